@@ -1,0 +1,487 @@
+// Shared-MLP layer (1x1 convolution / fully connected) on the gfx950 fp32
+// matrix cores, with bias + folded batch norm + ReLU and the max-pool over
+// points fused into the epilogue, plus the Flipout forms of the same layer.
+//
+// Tiling.  A workgroup of 4 waves owns a 128-row x BN-column output tile
+// (BN = 128, 64 or 32) and walks K in steps of 32 through double-buffered LDS
+// tiles (one barrier per step; the global loads of step t+1 are in flight while
+// step t multiplies).  Each wave owns TM x TN accumulator tiles of 32x32 and
+// feeds v_mfma_f32_32x32x2_f32 from LDS:
+//   A operand  = activations  X[row = lane&31][k = 2s + (lane>>5)]
+//                LDS image [128][33] (row stride 33 words: the 32 rows of a
+//                half-wave read fall on 32 different banks)
+//   B operand  = weights      W[k = 2s + (lane>>5)][col = lane&31]
+//                LDS image [32][BN] (a half-wave reads 32 consecutive words)
+//   C/D        = lane holds output column lane&31; register r holds row
+//                (r&3) + 8*(r>>2) + 4*(lane>>5)
+// so per-column epilogue constants (scale, shift) are one value per lane, the
+// max over points is a max over a lane's 16 registers plus one cross-half
+// exchange, and stores are 128-byte runs per half-wave.
+//
+// fp32 MFMA is an exact fp32 FMA chain in k order: results differ from a CPU
+// fp32 GEMM only by summation order.
+#include <algorithm>
+#include <cstdint>
+
+#include "fpn_common.h"
+
+namespace fpn {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMlpThreads = 256;
+constexpr int kBM = 128;  // rows per workgroup (all configurations)
+constexpr int kBK = 32;   // K per LDS tile
+constexpr int kXS = kBK + 1;
+
+enum { kPlain = 0, kFlipoutFold = 1, kFlipoutTwoPass = 2 };
+
+struct MlpParams {
+    long rows;
+    int cin, cout;
+    const float *x;
+    int ldx;
+    const float *w;        // (cin,cout); the mean weights in the Flipout modes
+    const float *w_delta;  // (cin,cout) perturbation of this launch's sample
+    const float *sign_in;  // (groups,cin)  +-1
+    const float *sign_out; // (groups,cout) +-1
+    const float *scale, *shift;
+    const float *group_bias;
+    int rows_per_group;
+    int relu;
+    int pool_rows;
+    float *y;
+    int ldy;
+    float *partial;  // (row blocks, cout) when pool_rows > kBM
+};
+
+// MODE kPlain:        acc = x.w
+// MODE kFlipoutFold:  every row of the workgroup belongs to one sign group g, so
+//                     x.w + ((x*si).wd)*so == x.(w + si^T * wd * so): the
+//                     perturbation is folded into the weight tile while it is
+//                     staged (sign flips are exact) and the layer costs one
+//                     product instead of two.
+// MODE kFlipoutTwoPass: any grouping (fully connected layers: one group per
+//                     row).  K is walked twice: first (x*si).wd, then the
+//                     accumulators are multiplied by so, then x.w is added on
+//                     top - no second accumulator set.
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams p)
+{
+    constexpr int BN = WN * TN * 32;
+    static_assert(WM * TM * 32 == kBM, "row tile is fixed at 128");
+    static_assert(WM * WN * kWave == kMlpThreads, "4 waves");
+    constexpr int XREG = kBM * kBK / kMlpThreads;  // 16 floats of X per thread per tile
+    constexpr int WREG = kBK * BN / kMlpThreads;   // 16 / 8 / 4 floats of W
+    constexpr int NQ4 = BN / 4;                    // float4 per W tile row
+    constexpr int WROWS = kMlpThreads / NQ4;       // W tile rows per staging pass
+
+    __shared__ float Xs[2][kBM * kXS];
+    __shared__ __attribute__((aligned(16))) float Ws[2][kBK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int ncb = (p.cout + BN - 1) / BN;
+    const long row0 = (long)(blockIdx.x / ncb) * kBM;
+    const int col0 = (int)(blockIdx.x % ncb) * BN;
+
+    const bool xvec = (p.ldx % 4 == 0) && (p.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    const bool wvec = (p.cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0) &&
+                      (MODE == kPlain || (reinterpret_cast<uintptr_t>(p.w_delta) & 15) == 0);
+
+    const int ktiles = (p.cin + kBK - 1) / kBK;
+    const int passes = MODE == kFlipoutTwoPass ? 2 : 1;
+    const int total_tiles = ktiles * passes;
+
+    // sign group of the whole workgroup (fold mode)
+    const long gblock = MODE == kFlipoutFold ? row0 / p.rows_per_group : 0;
+
+    float xr[XREG];
+    float wr[WREG];
+
+    // ---- global -> register staging of tile t ---------------------------------
+    auto load_tile = [&](int t) {
+        const int pass = t / ktiles;                 // two-pass mode: 0 = perturbation, 1 = mean
+        const int k0 = (t - pass * ktiles) * kBK;
+        const bool perturb = MODE == kFlipoutTwoPass && pass == 0;
+        // X
+        if (xvec) {
+            const int kq = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < XREG / 4; ++i) {
+                const long row = row0 + r + 32 * i;
+                const int k = k0 + 4 * kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < p.rows && k < p.cin) {
+                    v = *reinterpret_cast<const float4 *>(p.x + row * p.ldx + k);
+                    if (perturb) {
+                        const float *si = p.sign_in + (row / p.rows_per_group) * p.cin + k;
+                        v.x *= si[0]; v.y *= si[1]; v.z *= si[2]; v.w *= si[3];
+                    }
+                }
+                xr[4 * i + 0] = v.x; xr[4 * i + 1] = v.y; xr[4 * i + 2] = v.z; xr[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XREG; ++i) {
+                const int e = tid + kMlpThreads * i;
+                const long row = row0 + (e >> 5);
+                const int k = k0 + (e & 31);
+                float v = 0.f;
+                if (row < p.rows && k < p.cin) {
+                    v = p.x[row * p.ldx + k];
+                    if (perturb) v *= p.sign_in[(row / p.rows_per_group) * p.cin + k];
+                }
+                xr[i] = v;
+            }
+        }
+        // W
+        const float *wsrc = perturb ? p.w_delta : p.w;
+        if (wvec) {
+            const int c4 = tid % NQ4, kr = tid / NQ4;
+            const int col = col0 + 4 * c4;
+#pragma unroll
+            for (int i = 0; i < WREG / 4; ++i) {
+                const int k = k0 + kr + WROWS * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < p.cin && col < p.cout) {
+                    v = *reinterpret_cast<const float4 *>(wsrc + (long)k * p.cout + col);
+                    if (MODE == kFlipoutFold) {
+                        const float4 d = *reinterpret_cast<const float4 *>(p.w_delta + (long)k * p.cout + col);
+                        const float si = p.sign_in[gblock * p.cin + k];
+                        const float *so = p.sign_out + gblock * p.cout + col;
+                        v.x += si * d.x * so[0];
+                        v.y += si * d.y * so[1];
+                        v.z += si * d.z * so[2];
+                        v.w += si * d.w * so[3];
+                    }
+                }
+                wr[4 * i + 0] = v.x; wr[4 * i + 1] = v.y; wr[4 * i + 2] = v.z; wr[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) {
+                const int e = tid + kMlpThreads * i;
+                const int k = k0 + e / BN;
+                const int col = col0 + e % BN;
+                float v = 0.f;
+                if (k < p.cin && col < p.cout) {
+                    v = wsrc[(long)k * p.cout + col];
+                    if (MODE == kFlipoutFold)
+                        v += p.sign_in[gblock * p.cin + k] * p.w_delta[(long)k * p.cout + col] *
+                             p.sign_out[gblock * p.cout + col];
+                }
+                wr[i] = v;
+            }
+        }
+    };
+
+    // ---- register -> LDS ------------------------------------------------------
+    auto store_tile = [&](int buf) {
+        float *xs = Xs[buf];
+        float *ws = Ws[buf];
+        if (xvec) {
+            const int kq = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < XREG / 4; ++i) {
+                float *dst = xs + (r + 32 * i) * kXS + 4 * kq;
+                dst[0] = xr[4 * i + 0]; dst[1] = xr[4 * i + 1]; dst[2] = xr[4 * i + 2]; dst[3] = xr[4 * i + 3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XREG; ++i) {
+                const int e = tid + kMlpThreads * i;
+                xs[(e >> 5) * kXS + (e & 31)] = xr[i];
+            }
+        }
+        if (wvec) {
+            const int c4 = tid % NQ4, kr = tid / NQ4;
+#pragma unroll
+            for (int i = 0; i < WREG / 4; ++i)
+                *reinterpret_cast<float4 *>(ws + (kr + WROWS * i) * BN + 4 * c4) =
+                    make_float4(wr[4 * i + 0], wr[4 * i + 1], wr[4 * i + 2], wr[4 * i + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) {
+                const int e = tid + kMlpThreads * i;
+                ws[e] = wr[i];
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < total_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < total_tiles) load_tile(t + 1);
+
+        if (MODE == kFlipoutTwoPass && t == ktiles) {
+            // perturbation product finished: multiply by the output signs of each
+            // row's group, then keep accumulating the mean product on top
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int col = col0 + (wn * TN + b) * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long row = row0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float so = 1.f;
+                        if (row < p.rows && col < p.cout)
+                            so = p.sign_out[(row / p.rows_per_group) * p.cout + col];
+                        acc[a][b][r] *= so;
+                    }
+                }
+        }
+
+        const float *xs = Xs[buf] + (wm * TM * 32 + l31) * kXS + half;
+        const float *ws = Ws[buf] + half * BN + wn * TN * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < kBK / 2; ++s) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = xs[a * 32 * kXS + 2 * s];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[b] = ws[2 * s * BN + b * 32];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+
+        if (t + 1 < total_tiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------
+    float *red = Xs[0];  // (kBM/32, BN) tile maxima; the K loop ended on a barrier
+    const bool pooled = p.pool_rows > 0;
+    const bool gb_tile_uniform = p.group_bias && (p.rows_per_group % 32 == 0);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = col0 + (wn * TN + b) * 32 + l31;
+        const bool colok = col < p.cout;
+        const float sc = (colok && p.scale) ? p.scale[col] : 1.f;
+        const float sh = (colok && p.shift) ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int trow = (wm * TM + a) * 32;  // tile's first row inside the block
+            float gbu = 0.f;
+            if (gb_tile_uniform && colok && row0 + trow < p.rows)
+                gbu = p.group_bias[((row0 + trow) / p.rows_per_group) * p.cout + col];
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + trow + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[a][b][r];
+                if (p.group_bias) {
+                    if (gb_tile_uniform) v += gbu;
+                    else if (colok && row < p.rows) v += p.group_bias[(row / p.rows_per_group) * p.cout + col];
+                }
+                v = v * sc + sh;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (pooled) m = fmaxf(m, v);
+                else if (colok && row < p.rows) p.y[row * p.ldy + col] = v;
+            }
+            if (pooled) {
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (half == 0) red[(wm * TM + a) * BN + (wn * TN + b) * 32 + l31] = m;
+            }
+        }
+    }
+    if (!pooled) return;
+    __syncthreads();
+    // rows is a multiple of pool_rows and pool_rows of 32: a 32-row tile is
+    // either all real rows or all padding
+    const int col = col0 + tid;
+    if (tid < BN && col < p.cout) {
+        if (p.pool_rows <= kBM) {
+            const int tiles_per_group = p.pool_rows / 32;
+            for (int g = 0; g < kBM / p.pool_rows; ++g) {
+                const long grow = row0 + (long)g * p.pool_rows;
+                if (grow >= p.rows) break;
+                float m = red[g * tiles_per_group * BN + tid];
+                for (int u = 1; u < tiles_per_group; ++u) m = fmaxf(m, red[(g * tiles_per_group + u) * BN + tid]);
+                p.y[(grow / p.pool_rows) * p.ldy + col] = m;
+            }
+        } else {
+            float m = red[tid];
+            for (int u = 1; u < kBM / 32; ++u) m = fmaxf(m, red[u * BN + tid]);
+            p.partial[(row0 / kBM) * p.cout + col] = m;
+        }
+    }
+}
+
+// y[g,c] = max over the blocks_per_group partial rows of group g
+__global__ void pool_finish_kernel(long groups, int cout, int blocks_per_group,
+                                   const float *__restrict__ partial, float *__restrict__ y, int ldy)
+{
+    const long total = groups * cout;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long g = e / cout;
+        const int c = (int)(e % cout);
+        const float *src = partial + g * blocks_per_group * cout + c;
+        float m = src[0];
+        for (int u = 1; u < blocks_per_group; ++u) m = fmaxf(m, src[(long)u * cout]);
+        y[g * ldy + c] = m;
+    }
+}
+
+// stand-alone max over groups of pool_rows consecutive rows (any pool_rows):
+// one thread per (group, column), columns along the lanes
+__global__ void max_pool_rows_kernel(long groups, int c, int pool_rows, const float *__restrict__ x,
+                                     int ldx, float *__restrict__ y, int ldy)
+{
+    const long total = groups * c;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long g = e / c;
+        const int col = (int)(e % c);
+        const float *src = x + g * pool_rows * ldx + col;
+        float m = src[0];
+        for (int r = 1; r < pool_rows; ++r) m = fmaxf(m, src[(long)r * ldx]);
+        y[g * ldy + col] = m;
+    }
+}
+
+template <int MODE>
+int launch_mlp(const MlpParams &p, hipStream_t st)
+{
+    const long rb = (p.rows + kBM - 1) / kBM;
+    if (p.cout > 64) {
+        const long nblk = rb * ((p.cout + 127) / 128);
+        FPN_REQUIRE(nblk <= INT32_MAX, "shared_mlp: grid too large");
+        hipLaunchKernelGGL((shared_mlp_kernel<2, 2, 2, 2, MODE>), dim3((unsigned)nblk), dim3(kMlpThreads), 0, st, p);
+    } else if (p.cout > 32) {
+        hipLaunchKernelGGL((shared_mlp_kernel<4, 1, 1, 2, MODE>), dim3((unsigned)rb), dim3(kMlpThreads), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((shared_mlp_kernel<4, 1, 1, 1, MODE>), dim3((unsigned)rb), dim3(kMlpThreads), 0, st, p);
+    }
+    int rc = check_launch("fpn_shared_mlp");
+    if (rc != FPN_OK) return rc;
+    if (p.pool_rows > kBM) {
+        const long groups = p.rows / p.pool_rows;
+        const int blocks = (int)std::min<long>((groups * p.cout + 255) / 256, 65536);
+        hipLaunchKernelGGL(pool_finish_kernel, dim3(blocks), dim3(256), 0, st, groups, p.cout,
+                           p.pool_rows / kBM, p.partial, p.y, p.ldy);
+        rc = check_launch("fpn_shared_mlp(pool)");
+    }
+    return rc;
+}
+
+int check_common(const char *who, long rows, int cin, int cout, const float *x, int ldx, const float *w,
+                 int pool_rows, const float *y, int ldy, const void *workspace, size_t workspace_bytes)
+{
+    FPN_REQUIRE(rows >= 0 && cin >= 1 && cout >= 1, "%s: bad size rows=%ld cin=%d cout=%d", who, rows, cin, cout);
+    FPN_REQUIRE(ldx >= cin && ldy >= cout, "%s: row stride smaller than the channel count", who);
+    FPN_REQUIRE(x && w && y, "%s: null pointer", who);
+    if (pool_rows) {
+        FPN_REQUIRE(pool_rows > 0 && pool_rows % 32 == 0, "%s: pool_rows=%d must be a positive multiple of 32", who, pool_rows);
+        FPN_REQUIRE(rows % pool_rows == 0, "%s: rows=%ld is not a multiple of pool_rows=%d", who, rows, pool_rows);
+        if (pool_rows <= kBM) FPN_REQUIRE(kBM % pool_rows == 0, "%s: pool_rows=%d must be 32, 64 or a multiple of 128", who, pool_rows);
+        else {
+            FPN_REQUIRE(pool_rows % kBM == 0, "%s: pool_rows=%d must be 32, 64 or a multiple of 128", who, pool_rows);
+            FPN_REQUIRE(workspace && workspace_bytes >= fpn_shared_mlp_workspace_bytes(rows, cout, pool_rows),
+                        "%s: workspace too small (%zu bytes)", who, workspace_bytes);
+        }
+    }
+    return FPN_OK;
+}
+
+}  // namespace
+}  // namespace fpn
+
+using namespace fpn;
+
+extern "C" {
+
+size_t fpn_shared_mlp_workspace_bytes(long rows, int cout, int pool_rows)
+{
+    if (pool_rows <= kBM || rows <= 0 || cout <= 0) return 0;
+    return (size_t)((rows + kBM - 1) / kBM) * (size_t)cout * sizeof(float);
+}
+
+int fpn_max_pool_rows(long rows, int c, int pool_rows, const float *x, int ldx, float *y, int ldy,
+                      void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && c >= 1 && pool_rows >= 1, "max_pool_rows: bad size");
+    FPN_REQUIRE(rows % pool_rows == 0, "max_pool_rows: rows=%ld is not a multiple of pool_rows=%d", rows, pool_rows);
+    FPN_REQUIRE(ldx >= c && ldy >= c, "max_pool_rows: row stride smaller than the channel count");
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(x && y, "max_pool_rows: null pointer");
+    const long groups = rows / pool_rows;
+    const int blocks = (int)std::min<long>((groups * c + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(max_pool_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), groups, c,
+                       pool_rows, x, ldx, y, ldy);
+    return check_launch("fpn_max_pool_rows");
+}
+
+int fpn_shared_mlp_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w,
+                       const float *scale, const float *shift, const float *group_bias,
+                       int rows_per_group, int relu, int pool_rows, float *y, int ldy, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    int rc = check_common("shared_mlp", rows, cin, cout, x, ldx, w, pool_rows, y, ldy, workspace, workspace_bytes);
+    if (rc != FPN_OK) return rc;
+    if (group_bias) FPN_REQUIRE(rows_per_group >= 1, "shared_mlp: group_bias needs rows_per_group >= 1");
+    if (rows == 0) return FPN_OK;
+    MlpParams p{};
+    p.rows = rows; p.cin = cin; p.cout = cout; p.x = x; p.ldx = ldx; p.w = w;
+    p.scale = scale; p.shift = shift; p.group_bias = group_bias;
+    p.rows_per_group = group_bias ? rows_per_group : 1;
+    p.relu = relu; p.pool_rows = pool_rows; p.y = y; p.ldy = ldy;
+    p.partial = static_cast<float *>(workspace);
+    return launch_mlp<kPlain>(p, as_stream(stream));
+}
+
+int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w_mean,
+                               const float *w_delta, long rows_per_sample, const float *sign_in,
+                               const float *sign_out, int rows_per_group, const float *scale,
+                               const float *shift, int relu, int pool_rows, float *y, int ldy,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_common("shared_mlp_flipout", rows, cin, cout, x, ldx, w_mean, pool_rows, y, ldy, workspace, workspace_bytes);
+    if (rc != FPN_OK) return rc;
+    FPN_REQUIRE(w_delta && sign_in && sign_out, "shared_mlp_flipout: null pointer");
+    FPN_REQUIRE(rows_per_group >= 1 && rows_per_sample >= 1, "shared_mlp_flipout: rows_per_group / rows_per_sample must be >= 1");
+    FPN_REQUIRE(rows % rows_per_sample == 0 && rows_per_sample % rows_per_group == 0,
+                "shared_mlp_flipout: rows (%ld) must split into samples (%ld) and samples into groups (%d)",
+                rows, rows_per_sample, rows_per_group);
+    if (pool_rows) FPN_REQUIRE(rows_per_sample % pool_rows == 0, "shared_mlp_flipout: pool groups straddle samples");
+    if (rows == 0) return FPN_OK;
+    // one launch per Monte-Carlo sample: each has its own weight perturbation
+    const long nsamples = rows / rows_per_sample;
+    const bool fold = rows_per_group % kBM == 0;
+    const long groups_per_sample = rows_per_sample / rows_per_group;
+    for (long s = 0; s < nsamples; ++s) {
+        MlpParams p{};
+        p.rows = rows_per_sample; p.cin = cin; p.cout = cout;
+        p.x = x + s * rows_per_sample * ldx; p.ldx = ldx;
+        p.w = w_mean; p.w_delta = w_delta + s * (long)cin * cout;
+        p.sign_in = sign_in + s * groups_per_sample * cin;
+        p.sign_out = sign_out + s * groups_per_sample * cout;
+        p.scale = scale; p.shift = shift; p.group_bias = nullptr; p.rows_per_group = rows_per_group;
+        p.relu = relu; p.pool_rows = pool_rows; p.ldy = ldy;
+        p.y = y + (pool_rows ? (s * rows_per_sample / pool_rows) : s * rows_per_sample) * (long)ldy;
+        const size_t ws_per_sample = fpn_shared_mlp_workspace_bytes(rows_per_sample, cout, pool_rows);
+        p.partial = workspace ? reinterpret_cast<float *>(static_cast<char *>(workspace) + s * ws_per_sample) : nullptr;
+        rc = fold ? launch_mlp<kFlipoutFold>(p, as_stream(stream)) : launch_mlp<kFlipoutTwoPass>(p, as_stream(stream));
+        if (rc != FPN_OK) return rc;
+    }
+    return FPN_OK;
+}
+
+}  // extern "C"

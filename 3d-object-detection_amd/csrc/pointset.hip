@@ -1,0 +1,868 @@
+// Point-set operators of the Frustum-PointNet hot path for gfx950 (MI355X):
+// farthest point sampling, gather, ball query, grouping, three-NN, three-point
+// interpolation (separate and fused), partial selection sort, and the
+// mask -> centroid -> object-point gather step.
+//
+// This translation unit is compiled with -ffp-contract=off: the squared
+// distance is three rounded products summed left to right and the interpolation
+// is three rounded products summed left to right, the arithmetic a C compiler
+// without FMA contraction gives the reference's CPU loops.  sqrt and division
+// are the correctly rounded forms (hipcc default, also passed explicitly).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "fpn_common.h"
+
+namespace fpn {
+namespace {
+
+__device__ __forceinline__ float sqdist3(float x2, float y2, float z2, float x1, float y1, float z1)
+{
+    float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    float s = dx * dx + dy * dy;
+    return s + dz * dz;
+}
+
+// max over the 64 lanes of a wave for values that order as unsigned integers
+// (non-negative floats do).  Six DPP steps leave the result in lane 63:
+// row_shr 1/2/4/8 fold each 16-lane row into its last lane, row_bcast15 folds
+// rows 0->1 and 2->3, row_bcast31 folds the lower half into the upper.  Lanes a
+// step does not reach see their own value again (old == src), which is harmless
+// for an idempotent max.
+__device__ __forceinline__ unsigned wave_umax(unsigned v)
+{
+#define FPN_DPP_MAX(ctrl, rows)                                                      \
+    {                                                                                \
+        unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false); \
+        v = v > t ? v : t;                                                           \
+    }
+    FPN_DPP_MAX(0x111, 0xf)  // row_shr:1
+    FPN_DPP_MAX(0x112, 0xf)  // row_shr:2
+    FPN_DPP_MAX(0x114, 0xf)  // row_shr:4
+    FPN_DPP_MAX(0x118, 0xf)  // row_shr:8
+    FPN_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    FPN_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef FPN_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ---------------------------------------------------------------------------
+// Farthest point sampling.
+//
+// One workgroup per frustum.  The frustum's xyz is staged once in LDS (the
+// picked point's coordinates are re-read from there every iteration as an LDS
+// broadcast); each thread owns PPT CONSECUTIVE points and keeps their
+// coordinates and running min-distance in registers for the whole m-1
+// iterations.  Because ownership is blocked, "lower lane" and "lower wave" both
+// mean "lower point index", so the lowest-index tie-break is: strict > inside a
+// thread, the first lane of the ballot inside a wave, strict > over waves in
+// wave order.  One barrier per iteration (the wave results are double-buffered
+// by iteration parity); single-wave blocks need none.
+// ---------------------------------------------------------------------------
+template <int THREADS, int PPT>
+__global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float *__restrict__ inp,
+                                                      int *__restrict__ out)
+{
+    extern __shared__ float smem[];
+    constexpr int W = THREADS / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *pts = inp + (size_t)blockIdx.x * n * 3;
+    int *o = out + (size_t)blockIdx.x * m;
+
+    float *sxyz = smem;
+    unsigned *xval = reinterpret_cast<unsigned *>(smem + ((n * 3 + 3) & ~3));
+    int *xidx = reinterpret_cast<int *>(xval + 2 * W);
+
+    for (int i = tid; i < n * 3; i += THREADS) sxyz[i] = pts[i];
+    __syncthreads();
+
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    const int base = tid * PPT;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        int k = base + s;
+        bool valid = k < n;
+        px[s] = valid ? sxyz[k * 3 + 0] : 0.f;
+        py[s] = valid ? sxyz[k * 3 + 1] : 0.f;
+        pz[s] = valid ? sxyz[k * 3 + 2] : 0.f;
+        // slots past the end start at distance 0 with an index above every real
+        // point: they can tie only when every real point is at 0 too, and then
+        // point 0 (lower index) wins.
+        md[s] = valid ? 1e38f : 0.f;
+    }
+
+    int old = 0;
+    if (tid == 0) o[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = sxyz[old * 3 + 0], y1 = sxyz[old * 3 + 1], z1 = sxyz[old * 3 + 2];
+        float best = -1.f;
+        int besti = 0;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            float d = sqdist3(px[s], py[s], pz[s], x1, y1, z1);
+            float d2 = d < md[s] ? d : md[s];
+            md[s] = d2;
+            if (d2 > best) {
+                best = d2;
+                besti = base + s;
+            }
+        }
+        const unsigned key = __float_as_uint(best);
+        const unsigned wmax = wave_umax(key);
+        const unsigned long long tie = __ballot(key == wmax);
+        const int widx = __builtin_amdgcn_readlane(besti, (int)__builtin_ctzll(tie));
+        if (W == 1) {
+            old = widx;
+        } else {
+            const int buf = (j & 1) * W;
+            if (lane == 0) {
+                xval[buf + wave] = wmax;
+                xidx[buf + wave] = widx;
+            }
+            __syncthreads();
+            unsigned bv = xval[buf];
+            int bi = xidx[buf];
+#pragma unroll
+            for (int w = 1; w < W; ++w) {
+                unsigned v = xval[buf + w];
+                int vi = xidx[buf + w];
+                if (v > bv) {
+                    bv = v;
+                    bi = vi;
+                }
+            }
+            old = bi;
+        }
+        if (tid == 0) o[j] = old;
+    }
+}
+
+// FPS for frustums too large for the register-resident kernel: running
+// distances live in LDS (n floats), coordinates are re-read from global memory
+// (L2-resident) every iteration.  Same ownership and tie rules as above.
+constexpr int kFpsLargeThreads = 1024;
+__global__ __launch_bounds__(kFpsLargeThreads) void fps_large_kernel(int n, int m,
+                                                                     const float *__restrict__ inp,
+                                                                     int *__restrict__ out)
+{
+    extern __shared__ float smem[];
+    constexpr int W = kFpsLargeThreads / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *pts = inp + (size_t)blockIdx.x * n * 3;
+    int *o = out + (size_t)blockIdx.x * m;
+    float *smd = smem;
+    unsigned *xval = reinterpret_cast<unsigned *>(smem + ((n + 3) & ~3));
+    int *xidx = reinterpret_cast<int *>(xval + 2 * W);
+
+    const int chunk = (n + kFpsLargeThreads - 1) / kFpsLargeThreads;
+    const int k0 = tid * chunk, k1 = min(n, k0 + chunk);
+    for (int k = k0; k < k1; ++k) smd[k] = 1e38f;
+
+    int old = 0;
+    if (tid == 0) o[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+        float best = 0.f;  // a thread with no points reports (0, index >= n)
+        int besti = k0 < n ? k0 : n + tid;
+        bool first = true;
+        for (int k = k0; k < k1; ++k) {
+            float d = sqdist3(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2], x1, y1, z1);
+            float t = smd[k];
+            float d2 = d < t ? d : t;
+            smd[k] = d2;
+            if (first || d2 > best) {
+                best = d2;
+                besti = k;
+                first = false;
+            }
+        }
+        const unsigned key = __float_as_uint(best);
+        const unsigned wmax = wave_umax(key);
+        const unsigned long long tie = __ballot(key == wmax);
+        const int widx = __builtin_amdgcn_readlane(besti, (int)__builtin_ctzll(tie));
+        const int buf = (j & 1) * W;
+        if (lane == 0) {
+            xval[buf + wave] = wmax;
+            xidx[buf + wave] = widx;
+        }
+        __syncthreads();
+        unsigned bv = xval[buf];
+        int bi = xidx[buf];
+        for (int w = 1; w < W; ++w) {
+            unsigned v = xval[buf + w];
+            if (v > bv) {
+                bv = v;
+                bi = xidx[buf + w];
+            }
+        }
+        old = bi;
+        if (tid == 0) o[j] = old;
+    }
+}
+
+template <int THREADS, int PPT>
+int launch_fps(int b, int n, int m, const float *inp, int *out, hipStream_t st)
+{
+    size_t lds = (size_t)((n * 3 + 3) & ~3) * 4 + (size_t)4 * (THREADS / kWave) * 4;
+    hipLaunchKernelGGL((fps_kernel<THREADS, PPT>), dim3(b), dim3(THREADS), lds, st, n, m, inp, out);
+    return check_launch("fpn_farthest_point_sample");
+}
+
+// ---------------------------------------------------------------------------
+// gather_point: one thread per output point.
+// ---------------------------------------------------------------------------
+__global__ void gather_point_kernel(long total, int n, int m, const float *__restrict__ inp,
+                                    const int *__restrict__ idx, float *__restrict__ out)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long)gridDim.x * blockDim.x) {
+        long i = e / m;
+        int a = idx[e];
+        const float *src = inp + (i * n + a) * 3;
+        float *dst = out + e * 3;
+        dst[0] = src[0];
+        dst[1] = src[1];
+        dst[2] = src[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Ball query.
+//
+// Grid (query blocks, frustums).  A workgroup stages a tile of the frustum's
+// dataset points in LDS with coalesced loads, then each WAVE takes one query at
+// a time and sweeps the tile 64 points per step: every lane tests one point, a
+// ballot gives the hits of the step in index order, a hit's slot is the running
+// count plus the number of hits in lower lanes, and the sweep stops (for the
+// whole wave) once nsample slots are filled.  That reproduces "first nsample
+// points in index order" without any per-lane serial scan, and the row is
+// written in runs of consecutive slots.
+//
+// The accept test max(sqrtf(s),1e-20f) < radius is evaluated as s <= smax,
+// where smax (computed on the host with the correctly rounded sqrtf) is the
+// largest float whose square root is still below radius; sqrtf is monotonic, so
+// the two tests accept exactly the same set of s.  radius <= 1e-20f accepts
+// nothing (smax = -1).
+// ---------------------------------------------------------------------------
+constexpr int kQbThreads = 256;
+constexpr int kQbTile = 4096;  // dataset points per LDS tile (48 KiB)
+
+__global__ __launch_bounds__(kQbThreads) void query_ball_kernel(
+    int n, int m, float smax, int nsample, int qpb, const float *__restrict__ xyz1,
+    const float *__restrict__ xyz2, int *__restrict__ idx, int *__restrict__ pts_cnt)
+{
+    extern __shared__ float smem[];
+    constexpr int W = kQbThreads / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bi = blockIdx.y;
+    const float *data = xyz1 + (size_t)bi * n * 3;
+    const float *query = xyz2 + (size_t)bi * m * 3;
+    const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+
+    float *tile = smem;                                       // kQbTile*3 floats
+    int *s_cnt = reinterpret_cast<int *>(smem + kQbTile * 3); // qpb
+    int *s_first = s_cnt + qpb;                               // qpb
+
+    for (int q = q0 + tid; q < q1; q += kQbThreads) {
+        s_cnt[q - q0] = 0;
+        s_first[q - q0] = 0;
+    }
+
+    for (int t0 = 0; t0 < n; t0 += kQbTile) {
+        const int tn = min(kQbTile, n - t0);
+        __syncthreads();  // previous tile fully consumed (and state initialised)
+        for (int i = tid; i < tn * 3; i += kQbThreads) tile[i] = data[(size_t)t0 * 3 + i];
+        __syncthreads();
+
+        for (int q = q0 + wave; q < q1; q += W) {
+            int cnt = s_cnt[q - q0];
+            if (cnt >= nsample) continue;
+            int first = s_first[q - q0];
+            const float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
+            int *row = idx + ((size_t)bi * m + q) * nsample;
+            for (int kb = 0; kb < tn && cnt < nsample; kb += kWave) {
+                const int k = kb + lane;
+                bool hit = false;
+                if (k < tn) {
+                    float s = sqdist3(qx, qy, qz, tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2]);
+                    hit = s <= smax;
+                }
+                const unsigned long long hits = __ballot(hit);
+                if (hits) {
+                    if (cnt == 0) first = t0 + kb + (int)__builtin_ctzll(hits);
+                    const int slot = cnt + __popcll(hits & ((1ull << lane) - 1ull));
+                    if (hit && slot < nsample) row[slot] = t0 + k;
+                    cnt += __popcll(hits);
+                }
+            }
+            if (lane == 0) {
+                s_cnt[q - q0] = cnt;
+                s_first[q - q0] = first;
+            }
+        }
+    }
+
+    // pad short rows with the first hit (zeros for an empty ball), write counts
+    for (int q = q0 + wave; q < q1; q += W) {
+        // s_cnt/s_first of query q were written by lane 0 of this same wave:
+        // LDS operations of one wave execute in order, no workgroup barrier needed
+        __builtin_amdgcn_wave_barrier();
+        int cnt = min(s_cnt[q - q0], nsample);
+        const int first = s_first[q - q0];
+        int *row = idx + ((size_t)bi * m + q) * nsample;
+        for (int l = cnt + lane; l < nsample; l += kWave) row[l] = first;
+        if (pts_cnt && lane == 0) pts_cnt[(size_t)bi * m + q] = cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// group_point / three_interpolate share one thread mapping: LW lanes walk the
+// channels of a row (LW = power of two covering min(c,64)), 256/LW rows per
+// workgroup, so stores are contiguous runs of c floats per row and consecutive
+// rows are adjacent in memory.  No integer division by c.
+// ---------------------------------------------------------------------------
+constexpr int kRowThreads = 256;
+
+template <int LW>
+__global__ __launch_bounds__(kRowThreads) void group_point_kernel(
+    int b, int n, int c, int rows_per_batch, const float *__restrict__ points,
+    const int *__restrict__ idx, float *__restrict__ out)
+{
+    constexpr int RPB = kRowThreads / LW;
+    const int lx = threadIdx.x % LW, ly = threadIdx.x / LW;
+    for (int bi = blockIdx.y; bi < b; bi += gridDim.y) {
+        const float *p = points + (size_t)bi * n * c;
+        for (int r = blockIdx.x * RPB + ly; r < rows_per_batch; r += gridDim.x * RPB) {
+            const size_t row = (size_t)bi * rows_per_batch + r;
+            const int ii = idx[row];
+            const float *src = p + (size_t)ii * c;
+            float *dst = out + row * c;
+            for (int l = lx; l < c; l += LW) dst[l] = src[l];
+        }
+    }
+}
+
+template <int LW>
+__global__ __launch_bounds__(kRowThreads) void three_interpolate_kernel(
+    int b, int m, int c, int n, const float *__restrict__ points, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out)
+{
+    constexpr int RPB = kRowThreads / LW;
+    const int lx = threadIdx.x % LW, ly = threadIdx.x / LW;
+    for (int bi = blockIdx.y; bi < b; bi += gridDim.y) {
+        const float *p = points + (size_t)bi * m * c;
+        for (int r = blockIdx.x * RPB + ly; r < n; r += gridDim.x * RPB) {
+            const size_t row = (size_t)bi * n + r;
+            const int i1 = idx[row * 3 + 0], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
+            const float w1 = weight[row * 3 + 0], w2 = weight[row * 3 + 1], w3 = weight[row * 3 + 2];
+            const float *p1 = p + (size_t)i1 * c, *p2 = p + (size_t)i2 * c, *p3 = p + (size_t)i3 * c;
+            float *dst = out + row * c;
+            for (int l = lx; l < c; l += LW) {
+                float s = p1[l] * w1 + p2[l] * w2;
+                dst[l] = s + p3[l] * w3;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// three_nn: one lane per query point; the known points are staged in LDS as
+// float4 tiles and read by every lane as a broadcast, in index order, through
+// the reference's strict-"<" insertion cascade (branch-free).  Running bests
+// start at +inf: a float distance is never "<" +inf only when it is +inf or
+// NaN, the same inputs the reference's double 1e40 start rejects.
+// ---------------------------------------------------------------------------
+constexpr int kNnThreads = 256;
+constexpr int kNnTile = 2048;  // known points per LDS tile (32 KiB as float4)
+
+struct Best3 {
+    float d1, d2, d3;
+    int i1, i2, i3;
+};
+
+__device__ __forceinline__ void best3_init(Best3 &s)
+{
+    s.d1 = s.d2 = s.d3 = INFINITY;
+    s.i1 = s.i2 = s.i3 = 0;
+}
+
+__device__ __forceinline__ void best3_push(Best3 &s, float d, int k)
+{
+    const bool c1 = d < s.d1, c2 = d < s.d2, c3 = d < s.d3;
+    s.d3 = c2 ? s.d2 : (c3 ? d : s.d3);
+    s.i3 = c2 ? s.i2 : (c3 ? k : s.i3);
+    s.d2 = c1 ? s.d1 : (c2 ? d : s.d2);
+    s.i2 = c1 ? s.i1 : (c2 ? k : s.i2);
+    s.d1 = c1 ? d : s.d1;
+    s.i1 = c1 ? k : s.i1;
+}
+
+__device__ __forceinline__ void three_nn_scan(Best3 &s, bool active, float x1, float y1, float z1,
+                                              const float *__restrict__ known, int m, float4 *tile)
+{
+    for (int t0 = 0; t0 < m; t0 += kNnTile) {
+        const int tn = min(kNnTile, m - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += kNnThreads) {
+            const float *p = known + (size_t)(t0 + i) * 3;
+            tile[i] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 4
+            for (int k = 0; k < tn; ++k) {
+                const float4 p = tile[k];
+                best3_push(s, sqdist3(p.x, p.y, p.z, x1, y1, z1), t0 + k);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kNnThreads) void three_nn_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    float *__restrict__ dist, int *__restrict__ idx)
+{
+    __shared__ float4 tile[kNnTile];
+    const int bi = blockIdx.y;
+    const int j = blockIdx.x * kNnThreads + threadIdx.x;
+    const bool active = j < n;
+    const size_t row = (size_t)bi * n + (active ? j : 0);
+    const float x1 = xyz1[row * 3 + 0], y1 = xyz1[row * 3 + 1], z1 = xyz1[row * 3 + 2];
+    Best3 s;
+    best3_init(s);
+    three_nn_scan(s, active, x1, y1, z1, xyz2 + (size_t)bi * m * 3, m, tile);
+    if (active) {
+        dist[row * 3 + 0] = s.d1;
+        dist[row * 3 + 1] = s.d2;
+        dist[row * 3 + 2] = s.d3;
+        idx[row * 3 + 0] = s.i1;
+        idx[row * 3 + 1] = s.i2;
+        idx[row * 3 + 2] = s.i3;
+    }
+}
+
+// Fused three_nn + inverse-distance weights + three_interpolate.  Phase 1 is
+// the kernel above; each lane then turns its three distances into weights
+// (max(d,1e-10), reciprocal, left-to-right sum, divide: the op sequence of
+// pointnet_fp_module) and parks (indices, weights) in LDS; phase 2 has the
+// whole workgroup write the 256 output rows with lanes along the channel axis.
+template <int LW>
+__global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_kernel(
+    int n, int m, int c, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ points2, float *__restrict__ out, float *__restrict__ dist,
+    int *__restrict__ idx)
+{
+    __shared__ float4 tile[kNnTile];
+    __shared__ int s_i[kNnThreads * 3];
+    __shared__ float s_w[kNnThreads * 3];
+    const int bi = blockIdx.y;
+    const int j0 = blockIdx.x * kNnThreads;
+    const int j = j0 + threadIdx.x;
+    const bool active = j < n;
+    const size_t row = (size_t)bi * n + (active ? j : 0);
+    const float x1 = xyz1[row * 3 + 0], y1 = xyz1[row * 3 + 1], z1 = xyz1[row * 3 + 2];
+    Best3 s;
+    best3_init(s);
+    three_nn_scan(s, active, x1, y1, z1, xyz2 + (size_t)bi * m * 3, m, tile);
+
+    if (active) {
+        if (dist) {
+            dist[row * 3 + 0] = s.d1;
+            dist[row * 3 + 1] = s.d2;
+            dist[row * 3 + 2] = s.d3;
+        }
+        if (idx) {
+            idx[row * 3 + 0] = s.i1;
+            idx[row * 3 + 1] = s.i2;
+            idx[row * 3 + 2] = s.i3;
+        }
+    }
+    const float r1 = 1.0f / fmaxf(s.d1, 1e-10f);
+    const float r2 = 1.0f / fmaxf(s.d2, 1e-10f);
+    const float r3 = 1.0f / fmaxf(s.d3, 1e-10f);
+    float norm = r1 + r2;
+    norm = norm + r3;
+    s_i[threadIdx.x * 3 + 0] = s.i1;
+    s_i[threadIdx.x * 3 + 1] = s.i2;
+    s_i[threadIdx.x * 3 + 2] = s.i3;
+    s_w[threadIdx.x * 3 + 0] = r1 / norm;
+    s_w[threadIdx.x * 3 + 1] = r2 / norm;
+    s_w[threadIdx.x * 3 + 2] = r3 / norm;
+    __syncthreads();
+
+    constexpr int RPB = kNnThreads / LW;
+    const int lx = threadIdx.x % LW, ly = threadIdx.x / LW;
+    const float *p = points2 + (size_t)bi * m * c;
+    const int rows = min(kNnThreads, n - j0);
+    for (int r = ly; r < rows; r += RPB) {
+        const int i1 = s_i[r * 3 + 0], i2 = s_i[r * 3 + 1], i3 = s_i[r * 3 + 2];
+        const float w1 = s_w[r * 3 + 0], w2 = s_w[r * 3 + 1], w3 = s_w[r * 3 + 2];
+        const float *p1 = p + (size_t)i1 * c, *p2 = p + (size_t)i2 * c, *p3 = p + (size_t)i3 * c;
+        float *dst = out + ((size_t)bi * n + j0 + r) * c;
+        for (int l = lx; l < c; l += LW) {
+            float t = p1[l] * w1 + p2[l] * w2;
+            dst[l] = t + p3[l] * w3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Partial selection sort: one wave per (b,m) row, the row (values + indices)
+// resident in LDS.  Each of the k steps is a wave-wide arg-min over the tail
+// (lowest position on ties, like the reference's strict "<" scan) followed by
+// the reference's swap, so the WHOLE output row - not only its first k columns
+// - equals the reference's.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void selection_sort_kernel(int n, int k,
+                                                               const float *__restrict__ dist,
+                                                               int *__restrict__ outi,
+                                                               float *__restrict__ out)
+{
+    extern __shared__ float smem[];
+    float *v = smem;
+    int *ix = reinterpret_cast<int *>(smem + n);
+    const int lane = threadIdx.x;
+    const size_t row = blockIdx.x;
+    for (int s = lane; s < n; s += kWave) {
+        v[s] = dist[row * n + s];
+        ix[s] = s;
+    }
+    __syncthreads();
+    const int steps = min(k, n);
+    for (int s = 0; s < steps; ++s) {
+        // lane-local minimum over t = s+lane, s+lane+64, ...: first strict min
+        float bv = INFINITY;
+        int bt = n;  // n = "nothing found" (also covers NaN rows: nothing is < NaN)
+        bool any = false;
+        for (int t = s + lane; t < n; t += kWave) {
+            float x = v[t];
+            if (!any || x < bv) {
+                // a later t replaces only on strict "<"; the first t seeds
+                bv = x;
+                bt = t;
+                any = true;
+            }
+        }
+        // wave arg-min with lowest position on ties.  The reference compares
+        // p[t] < p[min] sequentially starting from min = s; a sequential scan
+        // with strict "<" returns the lowest position among the smallest
+        // values provided comparisons are a total order (no NaN).
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float ov = __shfl_xor(bv, off);
+            int ot = __shfl_xor(bt, off);
+            bool oany = ot < n;
+            bool take = oany && (!(bt < n) || ov < bv || (ov == bv && ot < bt));
+            bv = take ? ov : bv;
+            bt = take ? ot : bt;
+        }
+        if (lane == 0 && bt < n && bt != s) {
+            float tv = v[bt];
+            v[bt] = v[s];
+            v[s] = tv;
+            int ti = ix[bt];
+            ix[bt] = ix[s];
+            ix[s] = ti;
+        }
+        __syncthreads();
+    }
+    for (int s = lane; s < n; s += kWave) {
+        out[row * n + s] = v[s];
+        outi[row * n + s] = ix[s];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Mask -> centroid -> object-point selection -> centred gather, one workgroup
+// per frustum.  Each thread owns a contiguous chunk of points, so an exclusive
+// scan of the per-thread positive counts gives every positive its rank in index
+// order; ranks land in an LDS list from which the npick selections are read.
+// ---------------------------------------------------------------------------
+constexpr int kMgThreads = 256;
+constexpr int kMgMaxN = 16384;
+
+__global__ __launch_bounds__(kMgThreads) void mask_gather_kernel(
+    int n, int cpc, int npick, const float *__restrict__ pc, const float *__restrict__ logits,
+    float *__restrict__ mask, float *__restrict__ mean, int *__restrict__ sel,
+    float *__restrict__ obj)
+{
+    extern __shared__ int s_pos[];  // n entries: positives in index order
+    __shared__ int s_cnt[kMgThreads];
+    __shared__ float s_sum[kMgThreads][3];
+    __shared__ float s_mean[3];
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    const int bi = blockIdx.x;
+    const float *p = pc + (size_t)bi * n * cpc;
+    const float *lg = logits + (size_t)bi * n * 2;
+    const int chunk = (n + kMgThreads - 1) / kMgThreads;
+    const int k0 = min(n, tid * chunk), k1 = min(n, k0 + chunk);
+
+    int cnt = 0;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = k0; k < k1; ++k) {
+        const bool pos = lg[k * 2 + 0] < lg[k * 2 + 1];
+        if (mask) mask[(size_t)bi * n + k] = pos ? 1.f : 0.f;
+        if (pos) {
+            ++cnt;
+            sx += p[(size_t)k * cpc + 0];
+            sy += p[(size_t)k * cpc + 1];
+            sz += p[(size_t)k * cpc + 2];
+        }
+    }
+    s_cnt[tid] = cnt;
+    s_sum[tid][0] = sx;
+    s_sum[tid][1] = sy;
+    s_sum[tid][2] = sz;
+    __syncthreads();
+    // exclusive scan of the 256 counts and the coordinate sums by wave 0
+    if (tid < kWave) {
+        int c4[4];
+        int local = 0;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c4[u] = s_cnt[tid * 4 + u];
+            local += c4[u];
+            ax += s_sum[tid * 4 + u][0];
+            ay += s_sum[tid * 4 + u][1];
+            az += s_sum[tid * 4 + u][2];
+        }
+        int incl = local;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (tid >= off) incl += t;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ax += __shfl_xor(ax, off);
+            ay += __shfl_xor(ay, off);
+            az += __shfl_xor(az, off);
+        }
+        int run = incl - local;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s_cnt[tid * 4 + u] = run;
+            run += c4[u];
+        }
+        if (tid == kWave - 1) s_total = incl;
+        if (tid == 0) {
+            s_sum[0][0] = ax;
+            s_sum[0][1] = ay;
+            s_sum[0][2] = az;
+        }
+    }
+    __syncthreads();
+    const int total = s_total;
+    if (tid < 3) {
+        const float denom = total > 0 ? (float)total : 1.f;
+        const float mu = s_sum[0][tid] / denom;
+        s_mean[tid] = mu;
+        mean[(size_t)bi * 3 + tid] = mu;
+    }
+    int rank = s_cnt[tid];
+    for (int k = k0; k < k1; ++k)
+        if (lg[k * 2 + 0] < lg[k * 2 + 1]) s_pos[rank++] = k;
+    __syncthreads();
+    const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
+    for (int t = tid; t < npick; t += kMgThreads) {
+        int k = 0;
+        if (total > 0) k = s_pos[total >= npick ? t : t % total];
+        if (sel) sel[(size_t)bi * npick + t] = k;
+        float *dst = obj + ((size_t)bi * npick + t) * 3;
+        dst[0] = p[(size_t)k * cpc + 0] - mx;
+        dst[1] = p[(size_t)k * cpc + 1] - my;
+        dst[2] = p[(size_t)k * cpc + 2] - mz;
+    }
+}
+
+int pow2_at_least(int c)
+{
+    int lw = 1;
+    while (lw < c && lw < kWave) lw <<= 1;
+    return lw;
+}
+
+// Largest float s with max(sqrtf(s),1e-20f) < radius, or -1 when no s passes.
+float ball_threshold(float radius)
+{
+    if (!(radius > 1e-20f)) return -1.f;
+    if (std::isinf(radius) || radius > sqrtf(FLT_MAX)) return FLT_MAX;
+    float s = radius * radius;
+    if (std::isinf(s)) s = FLT_MAX;
+    while (s > 0.f && !(sqrtf(s) < radius)) s = nextafterf(s, -INFINITY);
+    for (;;) {
+        float up = nextafterf(s, INFINITY);
+        if (std::isinf(up) || !(sqrtf(up) < radius)) break;
+        s = up;
+    }
+    return s;
+}
+
+}  // namespace
+}  // namespace fpn
+
+using namespace fpn;
+
+extern "C" {
+
+// Exposed for the host-side test of the sqrt-free accept test (not part of the
+// operator surface; declared in tests only).
+float fpn_ball_threshold(float radius) { return ball_threshold(radius); }
+
+int fpn_farthest_point_sample(int b, int n, int m, const float *inp, int *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "farthest_point_sample: negative size (b=%d n=%d m=%d)", b, n, m);
+    if (b == 0 || m == 0) return FPN_OK;
+    FPN_REQUIRE(n >= 1, "farthest_point_sample: npoint > 0 needs at least one input point");
+    FPN_REQUIRE(inp && out, "farthest_point_sample: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (n <= 64) return launch_fps<64, 1>(b, n, m, inp, out, st);
+    if (n <= 128) return launch_fps<64, 2>(b, n, m, inp, out, st);
+    if (n <= 256) return launch_fps<64, 4>(b, n, m, inp, out, st);
+    if (n <= 512) return launch_fps<128, 4>(b, n, m, inp, out, st);
+    if (n <= 1024) return launch_fps<256, 4>(b, n, m, inp, out, st);
+    if (n <= 2048) return launch_fps<256, 8>(b, n, m, inp, out, st);
+    if (n <= 4096) return launch_fps<512, 8>(b, n, m, inp, out, st);
+    if (n <= 8192) return launch_fps<1024, 8>(b, n, m, inp, out, st);
+    if (n > 32768)
+        return fail(FPN_E_UNSUPPORTED, "farthest_point_sample: n=%d exceeds the 32768-point limit", n);
+    size_t lds = (size_t)((n + 3) & ~3) * 4 + (size_t)4 * (kFpsLargeThreads / kWave) * 4;
+    hipLaunchKernelGGL(fps_large_kernel, dim3(b), dim3(kFpsLargeThreads), lds, st, n, m, inp, out);
+    return check_launch("fpn_farthest_point_sample");
+}
+
+int fpn_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "gather_point: negative size");
+    long total = (long)b * m;
+    if (total == 0) return FPN_OK;
+    FPN_REQUIRE(inp && idx && out, "gather_point: null pointer");
+    int blocks = (int)std::min<long>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(gather_point_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), total, n, m,
+                       inp, idx, out);
+    return check_launch("fpn_gather_point");
+}
+
+int fpn_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                         const float *xyz2, int *idx, int *pts_cnt, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "query_ball_point: negative size");
+    FPN_REQUIRE(radius > 0.f, "QueryBallPoint expects positive radius");
+    FPN_REQUIRE(nsample > 0, "QueryBallPoint expects positive nsample");
+    if (b == 0 || m == 0) return FPN_OK;
+    FPN_REQUIRE(xyz1 && xyz2 && idx, "query_ball_point: null pointer");
+    FPN_REQUIRE(b <= 65535, "query_ball_point: batch %d exceeds 65535", b);
+    // queries per workgroup: enough workgroups to cover the chip several times
+    // over, but not so few queries that the tile staging dominates
+    long want = ((long)b * m + 2047) / 2048;
+    int qpb = (int)std::min<long>(std::max<long>(want, 4), 64);
+    qpb = (qpb + 3) & ~3;
+    size_t lds = (size_t)kQbTile * 3 * 4 + (size_t)qpb * 2 * 4;
+    dim3 grid((m + qpb - 1) / qpb, b);
+    hipLaunchKernelGGL(query_ball_kernel, grid, dim3(kQbThreads), lds, as_stream(stream), n, m,
+                       ball_threshold(radius), nsample, qpb, xyz1, xyz2, idx, pts_cnt);
+    return check_launch("fpn_query_ball_point");
+}
+
+#define FPN_DISPATCH_LW(lw, KERNEL, ...)                                             \
+    switch (lw) {                                                                    \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;                     \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break;                     \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;                     \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                     \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                   \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;                   \
+    default: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;                   \
+    }
+
+int fpn_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                    float *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0 && nsample >= 0, "group_point: negative size");
+    long rows = (long)m * nsample;
+    if (b == 0 || rows == 0 || c == 0) return FPN_OK;
+    FPN_REQUIRE(points && idx && out, "group_point: null pointer");
+    FPN_REQUIRE(rows <= INT32_MAX, "group_point: m*nsample too large");
+    const int lw = pow2_at_least(c);
+    const int rpb = kRowThreads / lw;
+    dim3 grid((unsigned)std::min<long>((rows + rpb - 1) / rpb, 1 << 20), (unsigned)std::min(b, 65535));
+    hipStream_t st = as_stream(stream);
+    FPN_DISPATCH_LW(lw, group_point_kernel, grid, dim3(kRowThreads), 0, st, b, n, c, (int)rows, points,
+                    idx, out)
+    return check_launch("fpn_group_point");
+}
+
+int fpn_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+                 void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "three_nn: negative size");
+    if (b == 0 || n == 0) return FPN_OK;
+    FPN_REQUIRE(xyz1 && dist && idx && (xyz2 || m == 0), "three_nn: null pointer");
+    FPN_REQUIRE(b <= 65535, "three_nn: batch %d exceeds 65535", b);
+    dim3 grid((n + kNnThreads - 1) / kNnThreads, b);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(kNnThreads), 0, as_stream(stream), n, m, xyz1, xyz2,
+                       dist, idx);
+    return check_launch("fpn_three_nn");
+}
+
+int fpn_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                          const float *weight, float *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0, "three_interpolate: negative size");
+    if (b == 0 || n == 0 || c == 0) return FPN_OK;
+    FPN_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
+    const int lw = pow2_at_least(c);
+    const int rpb = kRowThreads / lw;
+    dim3 grid((unsigned)std::min<long>(((long)n + rpb - 1) / rpb, 1 << 20), (unsigned)std::min(b, 65535));
+    hipStream_t st = as_stream(stream);
+    FPN_DISPATCH_LW(lw, three_interpolate_kernel, grid, dim3(kRowThreads), 0, st, b, m, c, n, points, idx,
+                    weight, out)
+    return check_launch("fpn_three_interpolate");
+}
+
+int fpn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
+                             const float *points2, float *out, float *dist, int *idx, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 1, "three_nn_interpolate: bad size (m must be >= 1)");
+    if (b == 0 || n == 0) return FPN_OK;
+    FPN_REQUIRE(xyz1 && xyz2 && points2 && out, "three_nn_interpolate: null pointer");
+    FPN_REQUIRE(b <= 65535, "three_nn_interpolate: batch %d exceeds 65535", b);
+    const int lw = pow2_at_least(c > 0 ? c : 1);
+    dim3 grid((n + kNnThreads - 1) / kNnThreads, b);
+    hipStream_t st = as_stream(stream);
+    FPN_DISPATCH_LW(lw, three_nn_interpolate_kernel, grid, dim3(kNnThreads), 0, st, n, m, c, xyz1, xyz2,
+                    points2, out, dist, idx)
+    return check_launch("fpn_three_nn_interpolate");
+}
+
+int fpn_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "select_top_k: negative size");
+    FPN_REQUIRE(k > 0, "SelectionSort expects positive k");
+    long rows = (long)b * m;
+    if (rows == 0 || n == 0) return FPN_OK;
+    FPN_REQUIRE(dist && outi && out, "select_top_k: null pointer");
+    if (n > 16384) return fail(FPN_E_UNSUPPORTED, "select_top_k: n=%d exceeds the 16384-column limit", n);
+    FPN_REQUIRE(rows <= INT32_MAX, "select_top_k: too many rows");
+    hipLaunchKernelGGL(selection_sort_kernel, dim3((unsigned)rows), dim3(kWave), (size_t)n * 8,
+                       as_stream(stream), n, k, dist, outi, out);
+    return check_launch("fpn_select_top_k");
+}
+
+int fpn_mask_gather(int b, int n, int cpc, int npick, const float *point_cloud, const float *logits,
+                    float *mask, float *mean, int *sel, float *obj, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 1 && cpc >= 3 && npick >= 1, "mask_gather: bad size (n=%d cpc=%d npick=%d)", n, cpc, npick);
+    if (b == 0) return FPN_OK;
+    FPN_REQUIRE(point_cloud && logits && mean && obj, "mask_gather: null pointer");
+    if (n > kMgMaxN) return fail(FPN_E_UNSUPPORTED, "mask_gather: n=%d exceeds %d", n, kMgMaxN);
+    hipLaunchKernelGGL(mask_gather_kernel, dim3(b), dim3(kMgThreads), (size_t)n * 4, as_stream(stream), n,
+                       cpc, npick, point_cloud, logits, mask, mean, sel, obj);
+    return check_launch("fpn_mask_gather");
+}
+
+}  // extern "C"

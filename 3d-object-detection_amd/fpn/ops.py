@@ -1,0 +1,102 @@
+"""Thin tensor-level callers of the shared-MLP and masking entry points."""
+import torch
+
+from . import _lib
+
+
+def _rows_view(x):
+    """(..., C) contiguous tensor -> (rows, C) view."""
+    return x.reshape(-1, x.shape[-1])
+
+
+def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=None,
+               rows_per_group=0, out=None, cin=None):
+    """One fused layer through fpn_shared_mlp_f32.
+
+    x (rows, ldx) float32 with the layer's inputs in columns [0,cin) (cin defaults
+    to w.shape[0]); w (cin,cout); scale/shift (cout,) or None; group_bias
+    (rows/rows_per_group, cout) or None.  pool_rows > 0 max-pools groups of
+    pool_rows consecutive rows.  `out` may be a (rows_out, ldy) view into a wider
+    buffer (stride(0) = ldy >= cout, unit column stride).
+    """
+    lib = _lib.load()
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D tensor with unit column stride")
+    rows, ldx = x.shape[0], x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
+    cin = w.shape[0] if cin is None else cin
+    cout = w.shape[1]
+    if x.shape[1] < cin or w.shape[0] != cin:
+        raise ValueError("x has %d columns, w is %s" % (x.shape[1], tuple(w.shape)))
+    rows_out = rows // pool_rows if pool_rows else rows
+    if out is None:
+        out = torch.empty((rows_out, cout), dtype=torch.float32, device=x.device)
+    if out.shape[0] != rows_out or out.shape[1] < cout or out.stride(1) != 1:
+        raise ValueError("out has shape %s, expected (%d, >=%d)" % (tuple(out.shape), rows_out, cout))
+    ldy = out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1])
+    ws = None
+    ws_bytes = lib.fpn_shared_mlp_workspace_bytes(rows, cout, pool_rows)
+    if ws_bytes:
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.fpn_shared_mlp_f32(rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(w), _lib.ptr(scale),
+                                          _lib.ptr(shift), _lib.ptr(group_bias), int(rows_per_group),
+                                          int(bool(relu)), int(pool_rows), _lib.ptr(out), ldy,
+                                          _lib.ptr(ws), ws_bytes, _lib.stream_of(x)))
+    return out
+
+
+def shared_mlp_flipout(x, w_mean, w_delta, rows_per_sample, sign_in, sign_out, rows_per_group,
+                       scale=None, shift=None, relu=True, pool_rows=0, out=None):
+    """Flipout layer through fpn_shared_mlp_flipout_f32: x (S*rows_per_sample, cin),
+    w_mean (cin,cout), w_delta (S,cin,cout), sign_in (groups,cin), sign_out
+    (groups,cout) with groups = rows / rows_per_group."""
+    lib = _lib.load()
+    rows, ldx = x.shape[0], x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
+    cin, cout = w_mean.shape
+    rows_out = rows // pool_rows if pool_rows else rows
+    if out is None:
+        out = torch.empty((rows_out, cout), dtype=torch.float32, device=x.device)
+    ldy = out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1])
+    ws = None
+    ws_bytes = lib.fpn_shared_mlp_workspace_bytes(rows, cout, pool_rows)
+    if ws_bytes:
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.fpn_shared_mlp_flipout_f32(
+            rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(w_mean), _lib.ptr(w_delta), int(rows_per_sample),
+            _lib.ptr(sign_in), _lib.ptr(sign_out), int(rows_per_group), _lib.ptr(scale), _lib.ptr(shift),
+            int(bool(relu)), int(pool_rows), _lib.ptr(out), ldy, _lib.ptr(ws), ws_bytes,
+            _lib.stream_of(x)))
+    return out
+
+
+def max_pool_rows(x, pool_rows, out=None):
+    """x (rows, C) -> (rows/pool_rows, C): max over groups of consecutive rows,
+    through fpn_max_pool_rows."""
+    rows, c = x.shape
+    ldx = x.stride(0) if rows > 1 else max(x.stride(0), c)
+    if out is None:
+        out = torch.empty((rows // pool_rows, c), dtype=torch.float32, device=x.device)
+    ldy = out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1])
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().fpn_max_pool_rows(rows, c, int(pool_rows), _lib.ptr(x), ldx, _lib.ptr(out),
+                                                 ldy, _lib.stream_of(x)))
+    return out
+
+
+def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True):
+    """point_cloud (B,N,C>=3), logits (B,N,2) -> mask (B,N), mean (B,3), sel
+    (B,npick) int32, obj (B,npick,3) through fpn_mask_gather."""
+    _lib.require_device_tensor("point_cloud", point_cloud, torch.float32, 3)
+    _lib.require_device_tensor("logits", logits, torch.float32, 3, 2)
+    b, n, c = point_cloud.shape
+    dev = point_cloud.device
+    mask = torch.empty((b, n), dtype=torch.float32, device=dev) if want_mask else None
+    mean = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    sel = torch.empty((b, npick), dtype=torch.int32, device=dev) if want_sel else None
+    obj = torch.empty((b, npick, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().fpn_mask_gather(b, n, c, int(npick), _lib.ptr(point_cloud), _lib.ptr(logits),
+                                               _lib.ptr(mask), _lib.ptr(mean), _lib.ptr(sel), _lib.ptr(obj),
+                                               _lib.stream_of(point_cloud)))
+    return mask, mean, sel, obj

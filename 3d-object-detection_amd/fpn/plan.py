@@ -1,0 +1,183 @@
+"""Planned execution of the Frustum-PointNet v1 graph.
+
+`V1Plan` runs the same network as models/frustum_pointnets_v1.py:141-188 (and its
+Keras / Flipout re-statements) as a fixed sequence of libfpn_hip.so calls:
+
+  * every layer is one fused call (matmul + bias + folded batch norm + ReLU), the
+    global max-pools are fused into the layer before them and write straight into
+    the concat buffers that the next layer reads, so no pooled / tiled / concatenated
+    tensor is ever materialised;
+  * conv6 is split: its input is [point_feat(64) | global_feat(1024) | one_hot(3)]
+    (frustum_pointnets_v1.py:64-66) and 1027 of those 1091 channels are the same
+    for every point of a frustum, so their product with W6[64:1091] is computed
+    once per frustum and enters the per-point layer as a per-frustum bias;
+  * the batch is processed in chunks of frustums sized so that a chunk's
+    activations stay resident in the 256 MiB Infinity Cache between layers.
+
+In Flipout mode (models/FPointNet_Bayes.py) S Monte-Carlo samples of every frustum
+are stacked along the row axis and go through the same kernels in one pass.
+"""
+import math
+
+import torch
+
+from . import model_util, ops, variables
+
+SEG_HEAD = [("conv1", 64), ("conv2", 64), ("conv3", 64), ("conv4", 128), ("conv5", 1024)]
+SEG_TAIL = [("conv6", 512), ("conv7", 256), ("conv8", 128), ("conv9", 128)]
+TNET_CONV = [("conv-reg1-stage1", 128), ("conv-reg2-stage1", 128), ("conv-reg3-stage1", 256)]
+TNET_FC = [("fc1-stage1", 256), ("fc2-stage1", 128)]
+BOX_CONV = [("conv-reg1", 128), ("conv-reg2", 128), ("conv-reg3", 256), ("conv-reg4", 512)]
+BOX_FC = [("fc1", 512), ("fc2", 256)]
+BOX_OUT = 3 + model_util.NUM_HEADING_BIN * 2 + model_util.NUM_SIZE_CLUSTER * 4   # 59
+
+
+def layer_table(pc_channels):
+    """(scope, cin, cout, has_bn_slot, relu) for every layer of the v1 topology."""
+    t = []
+    cin = pc_channels
+    for s, c in SEG_HEAD:
+        t.append((s, cin, c, True, True)); cin = c
+    cin = 64 + 1024 + 3
+    for s, c in SEG_TAIL:
+        t.append((s, cin, c, True, True)); cin = c
+    t.append(("conv10", cin, 2, False, False))
+    cin = 3
+    for s, c in TNET_CONV:
+        t.append((s, cin, c, True, True)); cin = c
+    cin += 3
+    for s, c in TNET_FC:
+        t.append((s, cin, c, True, True)); cin = c
+    t.append(("fc3-stage1", cin, 3, False, False))
+    cin = 3
+    for s, c in BOX_CONV:
+        t.append((s, cin, c, True, True)); cin = c
+    cin += 3
+    for s, c in BOX_FC:
+        t.append((s, cin, c, True, True)); cin = c
+    t.append(("fc3", cin, BOX_OUT, False, False))
+    return t
+
+
+def init_variables(store, pc_channels=4, bn=True):
+    """Create every variable of the v1 topology in `store` (Xavier weights, zero
+    biases, identity batch norm), in the reference's scope names."""
+    for scope, cin, cout, bn_slot, _ in layer_table(pc_channels):
+        store.get_variable(scope + "/weights", (cin, cout), "xavier")
+        store.get_variable(scope + "/biases", (cout,), "zeros")
+        if bn and bn_slot:
+            store.get_variable(scope + "/bn/gamma", (cout,), "ones")
+            store.get_variable(scope + "/bn/beta", (cout,), "zeros")
+            store.get_variable(scope + "/bn/moving_mean", (cout,), "zeros")
+            store.get_variable(scope + "/bn/moving_variance", (cout,), "ones")
+    return store
+
+
+class V1Plan:
+    def __init__(self, store, pc_channels=4, bn=True, chunk_frustums=None):
+        self.store = store
+        self.pc_channels = pc_channels
+        self.bn = bn
+        self.chunk_frustums = chunk_frustums
+        init_variables(store, pc_channels, bn)
+        self._version = None
+        self._prepare()
+
+    # folded parameters, re-derived when the store changes
+    def _prepare(self):
+        st = self.store
+        self.p = {}
+        for scope, cin, cout, bn_slot, relu in layer_table(self.pc_channels):
+            scale, shift = st.folded(scope, self.bn and bn_slot)
+            self.p[scope] = (st[scope + "/weights"], scale, shift, relu)
+        w6 = st["conv6/weights"]
+        self.w6_pt = w6[:64].contiguous()       # rows of point_feat
+        self.w6_glob = w6[64:].contiguous()     # rows of [global_feat | one_hot]
+        self._version = st.version
+
+    def _layer(self, x, scope, **kw):
+        w, scale, shift, relu = self.p[scope]
+        return ops.shared_mlp(x, w, scale, shift, relu=relu, **kw)
+
+    def default_chunk(self, n):
+        # largest per-point activation set alive at once is conv6's 512 floats in +
+        # 256 out: ~3.6 KB per point with the smaller buffers; keep a chunk near 96 MiB
+        per_frustum = n * 3700
+        return max(1, min(256, (96 << 20) // per_frustum))
+
+    def forward(self, point_cloud, one_hot_vec):
+        if self._version != self.store.version:
+            self._prepare()
+        b, n, c = point_cloud.shape
+        if c != self.pc_channels:
+            raise ValueError("point cloud has %d channels, plan was built for %d" % (c, self.pc_channels))
+        if n % 32 != 0:
+            raise ValueError("the fused max-pool needs the number of points per frustum to be a multiple of 32")
+        chunk = self.chunk_frustums or self.default_chunk(n)
+        outs = []
+        for s in range(0, b, chunk):
+            outs.append(self._forward_chunk(point_cloud[s:s + chunk], one_hot_vec[s:s + chunk]))
+        ep = {}
+        for k in outs[0]:
+            ep[k] = outs[0][k] if len(outs) == 1 else torch.cat([o[k] for o in outs], dim=0)
+        return ep
+
+    def _forward_chunk(self, pc, one_hot):
+        b, n, c = pc.shape
+        dev = pc.device
+        rows = b * n
+        m = model_util.NUM_OBJECT_POINT
+        x = pc.reshape(rows, c)
+
+        # --- instance segmentation net (frustum_pointnets_v1.py:20-90) -------------
+        a = self._layer(x, "conv1")
+        a = self._layer(a, "conv2")
+        point_feat = self._layer(a, "conv3")
+        a = self._layer(point_feat, "conv4")
+        gcat = torch.empty((b, 1024 + 3), dtype=torch.float32, device=dev)
+        self._layer(a, "conv5", pool_rows=n, out=gcat[:, :1024])      # conv5 + maxpool :57-62
+        gcat[:, 1024:] = one_hot                                        # concat one-hot :64
+        del a
+        # frustum-constant part of conv6: [global_feat | one_hot] . W6[64:]
+        gbias = ops.shared_mlp(gcat, self.w6_glob, None, None, relu=False)
+        _, scale6, shift6, _ = self.p["conv6"]
+        a = ops.shared_mlp(point_feat, self.w6_pt, scale6, shift6, relu=True,
+                           group_bias=gbias, rows_per_group=n)          # conv6 :68-71
+        del point_feat
+        a = self._layer(a, "conv7")
+        a = self._layer(a, "conv8")
+        a = self._layer(a, "conv9")
+        logits = self._layer(a, "conv10").reshape(b, n, 2)             # dropout = identity :84-89
+        del a
+
+        # --- masking (model_util.py:275-319) -----------------------------------------
+        mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
+
+        # --- T-Net (model_util.py:322-357) ---------------------------------------------
+        t = self._layer(obj.reshape(b * m, 3), "conv-reg1-stage1")
+        t = self._layer(t, "conv-reg2-stage1")
+        tcat = torch.empty((b, 256 + 3), dtype=torch.float32, device=dev)
+        self._layer(t, "conv-reg3-stage1", pool_rows=m, out=tcat[:, :256])
+        tcat[:, 256:] = one_hot
+        t = self._layer(tcat, "fc1-stage1")
+        t = self._layer(t, "fc2-stage1")
+        center_delta = self._layer(t, "fc3-stage1")
+        stage1_center = center_delta + mean                              # frustum_pointnets_v1.py:173
+        obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)     # :176-177
+
+        # --- box estimation net (frustum_pointnets_v1.py:93-138) ------------------------
+        t = self._layer(obj_new, "conv-reg1")
+        t = self._layer(t, "conv-reg2")
+        t = self._layer(t, "conv-reg3")
+        bcat = torch.empty((b, 512 + 3), dtype=torch.float32, device=dev)
+        self._layer(t, "conv-reg4", pool_rows=m, out=bcat[:, :512])
+        bcat[:, 512:] = one_hot
+        t = self._layer(bcat, "fc1")
+        t = self._layer(t, "fc2")
+        output = self._layer(t, "fc3")
+
+        ep = {"mask_logits": logits, "mask": mask, "object_point_indices": sel, "mask_xyz_mean": mean,
+              "center_delta": center_delta, "stage1_center": stage1_center, "box_output": output}
+        model_util.parse_output_to_tensors(output, ep)
+        ep["center"] = ep["center_boxnet"] + stage1_center               # :186
+        return ep

@@ -1,0 +1,76 @@
+"""Grouping operators: counterpart of models/tf_ops/grouping/tf_grouping.py."""
+import torch
+
+from .. import _lib
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """radius float, nsample int, xyz1 (B,N,3) dataset, xyz2 (B,M,3) queries ->
+    idx (B,M,nsample) int32, pts_cnt (B,M) int32.  Reference: tf_grouping.py:9-21
+    (Python argument order; the op itself takes xyz1, xyz2 first, :21); checks as
+    QueryBallPointGpuOp, tf_grouping.cpp:70-86."""
+    if not float(radius) > 0:
+        raise ValueError("QueryBallPoint expects positive radius")
+    if int(nsample) <= 0:
+        raise ValueError("QueryBallPoint expects positive nsample")
+    _lib.require_device_tensor("xyz1", xyz1, torch.float32, 3, 3)
+    _lib.require_device_tensor("xyz2", xyz2, torch.float32, 3, 3)
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("QueryBallPoint expects xyz1 and xyz2 with the same batch size")
+    _lib.same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _lib.check(_lib.load().fpn_query_ball_point(b, n, m, float(radius), int(nsample), _lib.ptr(xyz1),
+                                                    _lib.ptr(xyz2), _lib.ptr(idx), _lib.ptr(cnt),
+                                                    _lib.stream_of(xyz1)))
+    return idx, cnt
+
+
+def select_top_k(k, dist):
+    """k int, dist (B,M,N) float32 -> idx (B,M,N) int32, dist_out (B,M,N) float32;
+    the first k columns hold the k smallest of each row.  Reference:
+    tf_grouping.py:23-32; checks as SelectionSortGpuOp, tf_grouping.cpp:110-118."""
+    if int(k) <= 0:
+        raise ValueError("SelectionSort expects positive k")
+    _lib.require_device_tensor("dist", dist, torch.float32, 3)
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        _lib.check(_lib.load().fpn_select_top_k(b, n, m, int(k), _lib.ptr(dist), _lib.ptr(outi),
+                                                _lib.ptr(out), _lib.stream_of(dist)))
+    return outi, out
+
+
+def group_point(points, idx):
+    """points (B,N,C) float32, idx (B,M,nsample) int32 -> (B,M,nsample,C) float32.
+    Reference: tf_grouping.py:34-42; checks as GroupPointGpuOp,
+    tf_grouping.cpp:146-156."""
+    _lib.require_device_tensor("points", points, torch.float32, 3)
+    _lib.require_device_tensor("idx", idx, torch.int32, 3)
+    if idx.shape[0] != points.shape[0]:
+        raise ValueError("GroupPoint expects (batch_size, npoints, nsample) idx shape")
+    _lib.same_device(points, idx)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _lib.check(_lib.load().fpn_group_point(b, n, c, m, ns, _lib.ptr(points), _lib.ptr(idx),
+                                               _lib.ptr(out), _lib.stream_of(points)))
+    return out
+
+
+def knn_point(k, xyz1, xyz2):
+    """k int, xyz1 (B,N,C) dataset, xyz2 (B,M,C) queries -> val (B,M,k) squared
+    distances, idx (B,M,k) int32.  Reference: tf_grouping.py:49-74: the (B,M,N)
+    distance matrix sum((xyz1-xyz2)**2,-1) is built with ordinary tensor ops
+    (there: TF ops; here: torch ops on the device) and handed to select_top_k."""
+    _lib.require_device_tensor("xyz1", xyz1, torch.float32, 3)
+    _lib.require_device_tensor("xyz2", xyz2, torch.float32, 3)
+    diff = xyz1[:, None, :, :] - xyz2[:, :, None, :]
+    dist = (diff * diff).sum(-1).contiguous()
+    outi, out = select_top_k(k, dist)
+    return out[:, :, :k].contiguous(), outi[:, :, :k].contiguous()

@@ -1,0 +1,216 @@
+/*
+ * fpn.h - C ABI of libfpn_hip.so, the gfx950 (MI355X) implementation of the
+ * Frustum-PointNet point-set hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain C: ints, floats, raw device pointers, no C++ or torch types;
+ *   - every pointer is DEVICE memory on the current HIP device, dense row-major
+ *     (the layout TensorFlow gives the reference's tensors), float = IEEE fp32,
+ *     indices = int32;
+ *   - the caller owns every buffer (inputs, outputs, workspace): the library
+ *     never allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*, NULL = the default stream);
+ *   - return value: FPN_OK, or a negative FPN_E_* code; fpn_last_error_string()
+ *     then describes the failure (thread-local);
+ *   - inference only: no gradient entry points (the reference registers
+ *     gradients for GatherPoint/GroupPoint/ThreeInterpolate; they are training
+ *     code and not part of this path).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to
+ * the reference repository root).
+ */
+#ifndef FPN_H
+#define FPN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPN_OK 0
+#define FPN_E_INVALID_ARG (-1)   /* bad size, null pointer, unsupported shape  */
+#define FPN_E_LAUNCH (-2)        /* the HIP runtime rejected a launch          */
+#define FPN_E_UNSUPPORTED (-3)   /* valid request outside the implemented range */
+
+/* ABI version of this header (bumped on any signature change). */
+int fpn_abi_version(void);
+
+/* Message for the last non-OK return on the calling thread ("" if none). */
+const char *fpn_last_error_string(void);
+
+/*
+ * Farthest point sampling: out[i,0]=0, then m-1 greedy picks of the point with
+ * the largest running min squared distance, ties to the LOWEST point index.
+ * Replaces farthestpointsamplingLauncher(int b,int n,int m,const float* inp,
+ * float* temp,int* out), models/tf_ops/sampling/tf_sampling.cpp:94 (kernel
+ * tf_sampling_g.cu:105-170).  The (32,n) global scratch `temp` of the reference
+ * does not exist here: running distances live in registers / LDS.
+ *   inp (b,n,3) f32 -> out (b,m) i32.      Limits: 1 <= n <= 32768.
+ */
+int fpn_farthest_point_sample(int b, int n, int m, const float *inp, int *out, void *stream);
+
+/*
+ * out[i,j,:] = inp[i,idx[i,j],:].  Replaces gatherpointLauncher(int b,int n,
+ * int m,const float* inp,const int* idx,float* out), tf_sampling.cpp:125
+ * (kernel tf_sampling_g.cu:172-181).   inp (b,n,3), idx (b,m) -> out (b,m,3).
+ */
+int fpn_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out,
+                     void *stream);
+
+/*
+ * Ball query: for each query j of xyz2 the first `nsample` dataset indices k (in
+ * index order) with max(sqrtf(|xyz2[j]-xyz1[k]|^2),1e-20f) < radius; a short
+ * row is padded with its first hit; pts_cnt[j] = hits (<= nsample).  An empty
+ * ball gives an all-zero row and pts_cnt 0 (the reference leaves that row
+ * unwritten).  Replaces queryBallPointLauncher(int b,int n,int m,float radius,
+ * int nsample,const float* xyz1,const float* xyz2,int* idx,int* pts_cnt),
+ * models/tf_ops/grouping/tf_grouping.cpp:66 (kernel tf_grouping_g.cu:3-36; CPU
+ * twin query_ball_point.cpp:19-47).
+ *   xyz1 (b,n,3), xyz2 (b,m,3) -> idx (b,m,nsample) i32, pts_cnt (b,m) i32.
+ *   pts_cnt may be NULL.
+ */
+int fpn_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                         const float *xyz2, int *idx, int *pts_cnt, void *stream);
+
+/*
+ * out[i,j,k,:] = points[i,idx[i,j,k],:].  Replaces groupPointLauncher(int b,
+ * int n,int c,int m,int nsample,const float* points,const int* idx,float* out),
+ * tf_grouping.cpp:142 (kernel tf_grouping_g.cu:40-57; CPU twin
+ * query_ball_point.cpp:52-66).  points (b,n,c), idx (b,m,nsample) ->
+ * out (b,m,nsample,c).
+ */
+int fpn_group_point(int b, int n, int c, int m, int nsample, const float *points,
+                    const int *idx, float *out, void *stream);
+
+/*
+ * Three nearest neighbours by squared distance, ascending, ties to the lowest
+ * index; with m < 3 the missing slots are (+inf, 0).  Replaces threenn_cpu(int b,
+ * int n,int m,const float* xyz1,const float* xyz2,float* dist,int* idx),
+ * models/tf_ops/3d_interpolation/tf_interpolate.cpp:60-103 (the reference runs
+ * this op on the host only).  xyz1 (b,n,3), xyz2 (b,m,3) -> dist (b,n,3) f32,
+ * idx (b,n,3) i32.
+ */
+int fpn_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
+                 int *idx, void *stream);
+
+/*
+ * out[i,j,l] = p[i,idx0,l]*w0 + p[i,idx1,l]*w1 + p[i,idx2,l]*w2 (products
+ * rounded, summed left to right).  Replaces threeinterpolate_cpu(int b,int m,
+ * int c,int n,const float* points,const int* idx,const float* weight,float* out),
+ * tf_interpolate.cpp:107-127.  points (b,m,c), idx (b,n,3), weight (b,n,3) ->
+ * out (b,n,c).
+ */
+int fpn_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                          const float *weight, float *out, void *stream);
+
+/*
+ * Fused feature propagation front half: three_nn(xyz1,xyz2), the inverse-
+ * distance weights of models/pointnet_util.py:211-214 (dist=max(dist,1e-10),
+ * w=(1/dist)/sum(1/dist)), and three_interpolate(points2,idx,w) in one kernel;
+ * the neighbour table never goes to memory unless asked for.  Same results as
+ * the three separate steps.  dist / idx may be NULL (not written).
+ *   xyz1 (b,n,3), xyz2 (b,m,3), points2 (b,m,c) -> out (b,n,c),
+ *   optionally dist (b,n,3), idx (b,n,3).
+ * No single counterpart in the reference: it is pointnet_fp_module's
+ * lines :210-215 as one call.
+ */
+int fpn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
+                             const float *points2, float *out, float *dist, int *idx,
+                             void *stream);
+
+/*
+ * Partial selection sort of each row of dist (b,m,n): out = dist with the k
+ * smallest values of the row moved (by the reference's swap sequence) to the
+ * first k columns, outi = the matching permutation of 0..n-1.  Replaces
+ * selectionSortLauncher(int b,int n,int m,int k,const float* dist,int* outi,
+ * float* out), tf_grouping.cpp:108 (kernel tf_grouping_g.cu:83-123; CPU twin
+ * selection_sort.cpp:20-63).
+ */
+int fpn_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, float *out,
+                     void *stream);
+
+/*
+ * One shared-MLP layer (1x1 convolution / fully connected) with everything the
+ * reference applies after it fused in:
+ *     acc  = x[r, 0:cin] . w            (fp32 MFMA, exact fp32 FMA chain)
+ *     acc += group_bias[r / rows_per_group, :]        if group_bias != NULL
+ *     v    = acc * scale[:] + shift[:]                (NULL scale = 1, NULL shift = 0)
+ *     v    = max(v, 0)                                if relu
+ *     pool_rows == 0 : y[r, :] = v                    y is (rows, ldy)
+ *     pool_rows  > 0 : y[g, :] = max over the pool_rows consecutive rows of
+ *                      group g                        y is (rows/pool_rows, ldy)
+ * scale/shift carry bias + inference batch norm folded by the caller:
+ * scale = gamma/sqrt(var+eps), shift = beta + (bias-mean)*scale.
+ * Replaces, per layer, tf_util.conv2d (models/tf_util.py:120-185: conv2d :170,
+ * bias_add :176, batch norm :178-181, ReLU :183-184), tf_util.fully_connected
+ * (:327-363) and, with pool_rows, the tf_util.max_pool2d([N,1]) that follows
+ * (:366-389; models/frustum_pointnets_v1.py:61,124; model_util.py:347) or the
+ * reduce_max over nsample of pointnet_util.py:126,192.
+ *   x (rows, ldx) with ldx >= cin; w (cin, cout) row-major; y row stride ldy >=
+ *   cout (lets a layer write into a slice of a wider concat buffer).
+ *   pool_rows must be a multiple of 32 and divide rows.
+ *   workspace: needed only when pool_rows > 128; at least
+ *   fpn_shared_mlp_workspace_bytes(rows, cout, pool_rows) bytes.
+ */
+int fpn_shared_mlp_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w,
+                       const float *scale, const float *shift, const float *group_bias,
+                       int rows_per_group, int relu, int pool_rows, float *y, int ldy,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+size_t fpn_shared_mlp_workspace_bytes(long rows, int cout, int pool_rows);
+
+/*
+ * y[g,:] = max over the pool_rows consecutive rows of group g of x (rows, ldx):
+ * tf_util.max_pool2d with kernel [N,1] (models/tf_util.py:366-389) /
+ * tf.reduce_max over the sample axis (models/pointnet_util.py:126,192) as a
+ * stand-alone op, for callers that did not fuse it into the layer before it.
+ * Any pool_rows >= 1 dividing rows.  y is (rows/pool_rows, ldy).
+ */
+int fpn_max_pool_rows(long rows, int c, int pool_rows, const float *x, int ldx, float *y, int ldy,
+                      void *stream);
+
+/*
+ * Flipout form of the same layer (models/FPointNet_Bayes.py:54-68, which calls
+ * tfp.layers.Convolution2DFlipout / DenseFlipout):
+ *     acc = x . w_mean + ((x * sign_in[g]) . w_delta[s]) * sign_out[g]
+ * with g = r / rows_per_group (one sign pair per example) and s =
+ * r / rows_per_sample (one weight perturbation per Monte-Carlo sample, so S
+ * samples are batched as S*rows_per_sample rows of one launch); then the same
+ * scale/shift/relu/pool epilogue as fpn_shared_mlp_f32.
+ *   w_delta (nsamples, cin, cout); sign_in (rows/rows_per_group, cin) and
+ *   sign_out (rows/rows_per_group, cout) hold +1/-1 as f32.
+ */
+int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int ldx,
+                               const float *w_mean, const float *w_delta, long rows_per_sample,
+                               const float *sign_in, const float *sign_out, int rows_per_group,
+                               const float *scale, const float *shift, int relu, int pool_rows,
+                               float *y, int ldy, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
+/*
+ * Mask, masked centroid and object-point gather of point_cloud_masking +
+ * tf_gather_object_pc (models/model_util.py:275-319, :55-86), on the device
+ * (the reference leaves the graph for numpy through tf.py_func, :84):
+ *   mask[i,j]      = logits[i,j,0] < logits[i,j,1]            (as 0/1 f32)
+ *   mean[i,:]      = sum_j mask*xyz / max(count,1)
+ *   sel[i,0:npick] = indices of the object points: the first npick positives in
+ *                    index order when count >= npick, otherwise the positives
+ *                    repeated cyclically; all zero when count == 0.  (The
+ *                    reference draws this set with numpy's global RNG; for
+ *                    count <= npick the SET is the same, and the nets after it
+ *                    are invariant to order and repetition.)
+ *   obj[i,t,:]     = xyz[i,sel[i,t],:] - mean[i,:]
+ *   point_cloud (b,n,cpc) with xyz in channels 0..2; logits (b,n,2).
+ *   Outputs: mask (b,n) f32, mean (b,3), sel (b,npick) i32, obj (b,npick,3);
+ *   mask and sel may be NULL.  Limits: n <= 16384, npick <= n or any npick when
+ *   positives repeat.
+ */
+int fpn_mask_gather(int b, int n, int cpc, int npick, const float *point_cloud,
+                    const float *logits, float *mask, float *mean, int *sel, float *obj,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPN_H */

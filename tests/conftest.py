@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_PARENT = os.path.join(ROOT, "3d-object-detection_amd")
+for p in (ROOT, PKG_PARENT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm GPU (run on the MI355X box)")
+
+
+@pytest.fixture(scope="session")
+def device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    return torch.device("cuda:0")

@@ -1,0 +1,145 @@
+"""GPU parity of the shared-MLP layer and of the whole v1 network against the numpy
+oracle.
+
+Tolerance (floating point): the fp32 MFMA path and the numpy fp32 GEMM differ only
+by summation order; the bar is |got - want| <= 1e-3 * max(|want|, s) with s the
+tensor's RMS (the north-star 1e-3 relative bound, made robust to outputs that pass
+through zero).  In practice the error is ~1e-6 relative; a float64 evaluation of the
+oracle is used to show both fp32 results are equally close to the exact value.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import v1_numpy as V
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def close(got, want, rtol=RTOL):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    s = np.sqrt(np.mean(want ** 2)) + 1e-30
+    err = np.abs(got - want) / np.maximum(np.abs(want), s)
+    assert err.max() <= rtol, "max scaled error %.3e" % err.max()
+    return err.max()
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(256, 4, 64), (1000, 64, 64), (384, 64, 128), (512, 128, 1024),
+                                           (130, 1091, 512), (64, 515, 512), (777, 3, 128), (256, 128, 2),
+                                           (33, 256, 59), (128, 512, 256), (5, 259, 256)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_layer_matches_numpy(device, rows, cin, cout, relu):
+    from fpn import ops
+    rng = np.random.RandomState(rows + cin + cout)
+    x = rng.standard_normal((rows, cin)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32) * rng.choice([-1, 1], cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    want = (x.astype(np.float64) @ w.astype(np.float64)) * scale + shift
+    if relu:
+        want = np.maximum(want, 0)
+    got = ops.shared_mlp(dev(x, device), dev(w, device), dev(scale, device), dev(shift, device), relu=relu)
+    close(got.cpu().numpy(), want, 1e-4)
+
+
+@pytest.mark.parametrize("pool", [32, 64, 128, 256, 1024])
+def test_layer_pool_and_group_bias(device, pool):
+    from fpn import ops
+    rng = np.random.RandomState(pool)
+    groups, cin, cout = 5, 64, 200
+    rows = groups * pool
+    x = rng.standard_normal((rows, cin)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout)) / 8).astype(np.float32)
+    gb = rng.standard_normal((groups, cout)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    full = (x.astype(np.float64) @ w + np.repeat(gb, pool, 0)) * scale + shift
+    want = full.reshape(groups, pool, cout).max(1)
+    # written into a slice of a wider buffer (the concat-buffer use of the models)
+    wide = torch.zeros((groups, cout + 3), device=device)
+    ops.shared_mlp(dev(x, device), dev(w, device), dev(scale, device), dev(shift, device), relu=False,
+                   pool_rows=pool, group_bias=dev(gb, device), rows_per_group=pool, out=wide[:, :cout])
+    close(wide[:, :cout].cpu().numpy(), want, 1e-4)
+    assert (wide[:, cout:] == 0).all()
+    got = ops.max_pool_rows(dev(full.astype(np.float32), device), pool)
+    np.testing.assert_array_equal(got.cpu().numpy(), full.astype(np.float32).reshape(groups, pool, cout).max(1))
+
+
+def make_store(device, pc_channels=4, bn=True, seed=1):
+    from fpn import plan, variables
+    st = variables.VariableStore(device, seed=seed)
+    plan.init_variables(st, pc_channels, bn)
+    st.randomize_batch_norm(seed + 1)
+    return st
+
+
+def compare_end_points(ep, want, pc, one_hot, params, bn=True):
+    """Staged parity: logits; mask (flips allowed only where the two logits agree
+    to within the tolerance band); everything after the mask against the oracle
+    re-run on the GPU's mask, so a borderline point cannot hide a real error."""
+    logits = ep["mask_logits"].cpu().numpy()
+    close(logits, want["mask_logits"])
+    mask = ep["mask"].cpu().numpy()
+    flips = mask != want["mask"]
+    if flips.any():
+        wl = want["mask_logits"]
+        gap = np.abs(wl[..., 0] - wl[..., 1])[flips]
+        assert gap.max() <= RTOL * np.sqrt(np.mean(wl ** 2)), "mask differs away from the decision boundary"
+        want = V.get_model(pc, one_hot, params, bn=bn, mask_override=mask)
+    np.testing.assert_array_equal(ep["object_point_indices"].cpu().numpy(), want["object_point_indices"])
+    for k in ["mask_xyz_mean", "center_delta", "stage1_center", "box_output", "center_boxnet", "heading_scores",
+              "heading_residuals_normalized", "heading_residuals", "size_scores",
+              "size_residuals_normalized", "size_residuals", "center"]:
+        close(ep[k].cpu().numpy(), want[k])
+    return int(flips.sum())
+
+
+@pytest.mark.parametrize("literal", [False, True])
+def test_v1_get_model_config0(device, literal):
+    """BASELINE config 0: batch 32 x 1024 points, v1, against the CPU oracle."""
+    from fpn import synthetic, variables
+    from fpn.models import frustum_pointnets_v1 as M
+    pc, one_hot = synthetic.make_frustums(32, 1024, 4, seed=0)
+    st = make_store(device)
+    with variables.use_store(st):
+        ep = M.get_model(dev(pc, device), dev(one_hot, device), is_training=False, literal=literal)
+    params = st.numpy()
+    want = V.get_model(pc, one_hot, params)
+    assert ep["mask_logits"].shape == (32, 1024, 2) and ep["size_residuals"].shape == (32, 8, 3)
+    compare_end_points(ep, want, pc, one_hot, params)
+    # the segmentation must be non-trivial for the test to mean anything
+    cnt = want["mask"].sum(1)
+    assert (cnt > 0).any() and (cnt < 1024).any()
+
+
+def test_v1_chunking_and_sizes(device):
+    """Chunk boundaries do not change results; N=2048 and a ragged batch work."""
+    from fpn import plan, synthetic
+    st = make_store(device)
+    pc, one_hot = synthetic.make_frustums(7, 2048, 4, seed=3)
+    a = plan.V1Plan(st, 4, True, chunk_frustums=3).forward(dev(pc, device), dev(one_hot, device))
+    b = plan.V1Plan(st, 4, True, chunk_frustums=7).forward(dev(pc, device), dev(one_hot, device))
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    want = V.get_model(pc, one_hot, st.numpy())
+    compare_end_points(a, want, pc, one_hot, st.numpy())
+
+
+def test_v1_oracle_fp64_error_budget(device):
+    """Both fp32 evaluations (GPU, numpy) sit equally close to the float64 value."""
+    from fpn import plan, synthetic
+    st = make_store(device, seed=5)
+    pc, one_hot = synthetic.make_frustums(4, 1024, 4, seed=9)
+    ep = plan.V1Plan(st, 4, True).forward(dev(pc, device), dev(one_hot, device))
+    exact = V.get_model(pc, one_hot, st.numpy(), dtype=np.float64)
+    cpu32 = V.get_model(pc, one_hot, st.numpy(), dtype=np.float32)
+    e_gpu = close(ep["mask_logits"].cpu().numpy(), exact["mask_logits"], 1e-3)
+    e_cpu = close(cpu32["mask_logits"], exact["mask_logits"], 1e-3)
+    assert e_gpu < 1e-4 and e_cpu < 1e-4

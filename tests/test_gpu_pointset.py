@@ -1,0 +1,232 @@
+"""GPU parity of the point-set operators: the HIP path (through the C ABI, via the
+fpn.tf_ops wrappers) against the CPU oracle on the same seeded inputs.
+Bar: indices and copied values bit-exact; interpolated values bit-exact (same
+unfused fp32 operation order on both sides)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointset as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def clouds(b, n, seed, dup=0.0, scale=1.0):
+    rng = np.random.RandomState(seed)
+    x = (rng.random_sample((b, n, 3)) * scale).astype(np.float32)
+    ndup = int(dup * n)
+    for i in range(b):
+        if ndup:
+            dst = rng.permutation(n)[:ndup]
+            src = rng.randint(0, n, size=ndup)
+            x[i, dst] = x[i, src]
+    return x
+
+
+@pytest.mark.parametrize("n,npoint", [(1, 1), (1, 4), (64, 16), (100, 100), (129, 32), (512, 128),
+                                      (1000, 64), (1024, 128), (2048, 128), (3000, 40), (4096, 33),
+                                      (8192, 20), (9000, 12), (128, 32)])
+def test_fps_matches_oracle(device, n, npoint):
+    from fpn.tf_ops.tf_sampling import farthest_point_sample
+    x = clouds(3, n, seed=n + npoint, dup=0.1)
+    got = farthest_point_sample(npoint, dev(x, device)).cpu().numpy()
+    want = O.farthest_point_sample(npoint, x)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_fps_ties_lowest_index(device):
+    from fpn.tf_ops.tf_sampling import farthest_point_sample
+    # a lattice: many exactly equal distances; and an all-identical cloud
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(16), indexing="ij"), -1)
+    lattice = g.reshape(1, -1, 3).astype(np.float32)
+    same = np.ones((1, 1024, 3), np.float32) * 0.25
+    for x in (lattice, same, np.concatenate([lattice, lattice[:, ::-1]], 1)):
+        got = farthest_point_sample(64, dev(x, device)).cpu().numpy()
+        np.testing.assert_array_equal(got, O.farthest_point_sample(64, x))
+
+
+def test_fps_full_size_properties(device):
+    """BASELINE v2 size (2048 -> 128) on a large batch: first index 0, indices in
+    range, no repeats while distinct points remain, and equality with the oracle
+    on a sampled subset of frustums."""
+    from fpn.tf_ops.tf_sampling import farthest_point_sample
+    x = clouds(256, 2048, seed=7)
+    got = farthest_point_sample(128, dev(x, device)).cpu().numpy()
+    assert (got[:, 0] == 0).all() and got.min() >= 0 and got.max() < 2048
+    assert all(len(set(r)) == 128 for r in got)
+    sub = [0, 17, 100, 255]
+    np.testing.assert_array_equal(got[sub], O.farthest_point_sample(128, x[sub]))
+
+
+def test_gather_point(device):
+    from fpn.tf_ops.tf_sampling import gather_point
+    x = clouds(5, 777, seed=1)
+    idx = np.random.RandomState(2).randint(0, 777, size=(5, 300)).astype(np.int32)
+    got = gather_point(dev(x, device), dev(idx, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.gather_point(x, idx))
+
+
+@pytest.mark.parametrize("n,m,radius,nsample", [(128, 8, 0.3, 32), (512, 128, 0.1, 64), (2048, 128, 0.2, 32),
+                                                (2048, 128, 0.4, 64), (2048, 128, 0.8, 128), (128, 32, 1.6, 128),
+                                                (5000, 37, 0.15, 16), (9000, 5, 0.05, 8), (64, 64, 0.01, 4)])
+def test_query_ball_point(device, n, m, radius, nsample):
+    from fpn.tf_ops.tf_grouping import query_ball_point
+    x1 = clouds(3, n, seed=n + m, dup=0.05)
+    rng = np.random.RandomState(n * 3 + m)
+    # half of the queries are dataset points themselves (as inside an SA module)
+    x2 = clouds(3, m, seed=n + m + 1)
+    pick = rng.randint(0, n, size=(3, m))
+    own = rng.random_sample((3, m)) < 0.5
+    x2[own] = np.take_along_axis(x1, pick[..., None].repeat(3, 2), 1)[own]
+    idx, cnt = query_ball_point(radius, nsample, dev(x1, device), dev(x2, device))
+    widx, wcnt = O.query_ball_point(radius, nsample, x1, x2)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), widx)
+
+
+def test_query_ball_radius_boundary(device):
+    """Points at distances straddling the radius by single ulps: the sqrt-free
+    accept test must agree with sqrtf(d2) < r everywhere."""
+    from fpn.tf_ops.tf_grouping import query_ball_point
+    for r in (0.1, 0.2, 0.4, 0.8, 1.6, 0.3, 1e-3, 7.3, 123.456):
+        r32 = np.float32(r)
+        d = r32 * (1 + np.arange(-600, 600, dtype=np.float32) * np.float32(2.0 ** -24))
+        x1 = np.zeros((1, d.size, 3), np.float32)
+        x1[0, :, 0] = d
+        x1[0, 1::2, 0] *= -1
+        x2 = np.zeros((1, 1, 3), np.float32)
+        idx, cnt = query_ball_point(float(r32), 2000, dev(x1, device), dev(x2, device))
+        widx, wcnt = O.query_ball_point(float(r32), 2000, x1, x2)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
+        np.testing.assert_array_equal(idx.cpu().numpy(), widx)
+        assert 0 < wcnt[0, 0] < d.size
+
+
+def test_query_ball_empty(device):
+    from fpn.tf_ops.tf_grouping import query_ball_point
+    x1 = clouds(2, 100, seed=3)
+    x2 = clouds(2, 7, seed=4) + 10.0
+    idx, cnt = query_ball_point(0.5, 16, dev(x1, device), dev(x2, device))
+    assert (cnt.cpu().numpy() == 0).all() and (idx.cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize("c", [1, 3, 4, 16, 64, 67, 130])
+def test_group_point(device, c):
+    from fpn.tf_ops.tf_grouping import group_point
+    rng = np.random.RandomState(c)
+    pts = rng.standard_normal((3, 200, c)).astype(np.float32)
+    idx = rng.randint(0, 200, size=(3, 17, 9)).astype(np.int32)
+    got = group_point(dev(pts, device), dev(idx, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.group_point(pts, idx))
+
+
+@pytest.mark.parametrize("n,m", [(32, 1), (32, 2), (128, 32), (2048, 128), (300, 2500), (1, 3), (257, 5000)])
+def test_three_nn(device, n, m):
+    from fpn.tf_ops.tf_interpolate import three_nn
+    x1 = clouds(2, n, seed=n)
+    x2 = clouds(2, m, seed=m + 1, dup=0.2 if m > 10 else 0.0)
+    d, i = three_nn(dev(x1, device), dev(x2, device))
+    wd, wi = O.three_nn(x1, x2)
+    np.testing.assert_array_equal(i.cpu().numpy(), wi)
+    np.testing.assert_array_equal(d.cpu().numpy(), wd)
+
+
+@pytest.mark.parametrize("c", [1, 3, 64, 128, 259])
+def test_three_interpolate_and_fused(device, c):
+    from fpn.tf_ops.tf_interpolate import three_interpolate, three_nn, three_nn_interpolate
+    n, m = 700, 96
+    x1 = clouds(2, n, seed=c)
+    x2 = clouds(2, m, seed=c + 1)
+    p2 = np.random.RandomState(c + 2).standard_normal((2, m, c)).astype(np.float32)
+    wd, wi = O.three_nn(x1, x2)
+    ww = O.fp_weights(wd)
+    want = O.three_interpolate(p2, wi, ww)
+    got = three_interpolate(dev(p2, device), dev(wi, device), dev(ww, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    out, d, i = three_nn_interpolate(dev(x1, device), dev(x2, device), dev(p2, device), return_neighbours=True)
+    np.testing.assert_array_equal(i.cpu().numpy(), wi)
+    np.testing.assert_array_equal(d.cpu().numpy(), wd)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    out2 = three_nn_interpolate(dev(x1, device), dev(x2, device), dev(p2, device))
+    np.testing.assert_array_equal(out2.cpu().numpy(), want)
+
+
+def test_fused_interpolate_exact_hit_and_few_known(device):
+    """A query that coincides with a known point (distance 0 -> floor 1e-10) and
+    m < 3 (+inf distances -> weight 0)."""
+    from fpn.tf_ops.tf_interpolate import three_nn_interpolate
+    x2 = clouds(1, 2, seed=5)
+    x1 = np.concatenate([x2, clouds(1, 30, seed=6)], 1)
+    p2 = np.random.RandomState(7).standard_normal((1, 2, 8)).astype(np.float32)
+    wd, wi = O.three_nn(x1, x2)
+    want = O.three_interpolate(p2, wi, O.fp_weights(wd))
+    got = three_nn_interpolate(dev(x1, device), dev(x2, device), dev(p2, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert np.isfinite(got).all()
+
+
+def test_select_top_k(device):
+    from fpn.tf_ops.tf_grouping import knn_point, select_top_k
+    # the reference's own known-answer case (selection_sort.cpp:65-94)
+    dist = (10 - np.arange(16, dtype=np.float32)).reshape(2, 2, 4)
+    oi, ov = select_top_k(3, dev(dist, device))
+    wi, wv = O.select_top_k(3, dist)
+    np.testing.assert_array_equal(oi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(ov.cpu().numpy(), wv)
+    assert (wi[..., :4] == np.array([3, 2, 1, 0])).all()
+    rng = np.random.RandomState(0)
+    for (b, m, n, k) in [(2, 5, 100, 8), (1, 3, 1000, 128), (2, 2, 64, 64), (1, 4, 70, 1)]:
+        dist = rng.randint(0, 50, size=(b, m, n)).astype(np.float32)   # many ties
+        oi, ov = select_top_k(k, dev(dist, device))
+        wi, wv = O.select_top_k(k, dist)
+        np.testing.assert_array_equal(oi.cpu().numpy(), wi)
+        np.testing.assert_array_equal(ov.cpu().numpy(), wv)
+    x1 = clouds(2, 50, seed=11)
+    x2 = clouds(2, 6, seed=12)
+    val, idx = knn_point(4, dev(x1, device), dev(x2, device))
+    assert val.shape == (2, 6, 4) and idx.shape == (2, 6, 4)
+    d = ((x1[:, None] - x2[:, :, None]) ** 2).sum(-1)
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.argsort(d, axis=-1, kind="stable")[..., :4])
+
+
+def test_mask_gather(device):
+    from fpn import ops
+    from oracle import v1_numpy as V
+    rng = np.random.RandomState(5)
+    for (b, n, frac) in [(4, 1024, 0.3), (3, 2048, 0.6), (2, 96, 0.5), (2, 1024, 0.0), (2, 1024, 1.0)]:
+        pc = rng.standard_normal((b, n, 4)).astype(np.float32) * 10
+        logits = rng.standard_normal((b, n, 2)).astype(np.float32)
+        if frac == 0.0:
+            logits[..., 1] = logits[..., 0] - 1
+        elif frac == 1.0:
+            logits[..., 1] = logits[..., 0] + 1
+        else:
+            logits[..., 1] += np.float32(np.log(frac / (1 - frac)))
+        logits[0, :5, 1] = logits[0, :5, 0]      # exact ties are NOT object points (strict <)
+        mask, mean, sel, obj = ops.mask_gather(dev(pc, device), dev(logits, device), 512)
+        wobj, wmean, wmask, widx = V.point_cloud_masking(pc, logits)
+        np.testing.assert_array_equal(mask.cpu().numpy(), wmask)
+        np.testing.assert_array_equal(sel.cpu().numpy(), widx)
+        np.testing.assert_allclose(mean.cpu().numpy(), wmean, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(obj.cpu().numpy(), wobj, rtol=1e-5, atol=1e-4)
+
+
+def test_argument_errors(device):
+    from fpn.tf_ops import tf_grouping, tf_interpolate, tf_sampling
+    x = dev(clouds(1, 8, seed=0), device)
+    with pytest.raises(ValueError):
+        tf_sampling.farthest_point_sample(0, x)
+    with pytest.raises(ValueError):
+        tf_grouping.query_ball_point(-1.0, 4, x, x)
+    with pytest.raises(ValueError):
+        tf_grouping.query_ball_point(0.1, 0, x, x)
+    with pytest.raises(ValueError):
+        tf_interpolate.three_nn(x, x[..., :2].contiguous())
+    with pytest.raises(ValueError):
+        tf_sampling.farthest_point_sample(4, x.cpu())
+    with pytest.raises(ValueError):
+        tf_sampling.gather_point(x, torch.zeros((1, 2), dtype=torch.int64, device=device))
