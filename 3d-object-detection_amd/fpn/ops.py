@@ -4,9 +4,14 @@ import torch
 from . import _lib
 
 
-def _rows_view(x):
-    """(..., C) contiguous tensor -> (rows, C) view."""
-    return x.reshape(-1, x.shape[-1])
+# Optional observer of shared-MLP launches (the benchmark's per-kernel timer):
+# an object with begin(kernel_name, rows, cin, cout) -> token and end(token).
+launch_observer = None
+
+
+def mlp_kernel_name(cout):
+    """Which tile configuration fpn_shared_mlp_f32 launches for a layer width."""
+    return "shared_mlp_128x128" if cout > 64 else ("shared_mlp_128x64" if cout > 32 else "shared_mlp_128x32")
 
 
 def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=None,
@@ -37,11 +42,15 @@ def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=
     ws_bytes = lib.fpn_shared_mlp_workspace_bytes(rows, cout, pool_rows)
     if ws_bytes:
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    obs = launch_observer
+    tok = obs.begin(mlp_kernel_name(cout), rows, cin, cout) if obs is not None else None
     with torch.cuda.device(x.device):
         _lib.check(lib.fpn_shared_mlp_f32(rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(w), _lib.ptr(scale),
                                           _lib.ptr(shift), _lib.ptr(group_bias), int(rows_per_group),
                                           int(bool(relu)), int(pool_rows), _lib.ptr(out), ldy,
                                           _lib.ptr(ws), ws_bytes, _lib.stream_of(x)))
+    if obs is not None:
+        obs.end(tok)
     return out
 
 

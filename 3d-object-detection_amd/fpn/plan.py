@@ -100,10 +100,12 @@ class V1Plan:
         return ops.shared_mlp(x, w, scale, shift, relu=relu, **kw)
 
     def default_chunk(self, n):
-        # largest per-point activation set alive at once is conv6's 512 floats in +
-        # 256 out: ~3.6 KB per point with the smaller buffers; keep a chunk near 96 MiB
+        # largest per-point activation set alive at once is conv6's 512 floats out +
+        # conv7's 256: ~3.6 KB per point with the smaller buffers; a chunk of 1 GiB
+        # keeps the launch count low (the layers are compute-bound, so spilling the
+        # Infinity Cache costs little) while bounding the transient footprint
         per_frustum = n * 3700
-        return max(1, min(256, (96 << 20) // per_frustum))
+        return max(1, min(1024, (1 << 30) // per_frustum))
 
     def forward(self, point_cloud, one_hot_vec):
         if self._version != self.store.version:

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the Frustum-PointNet v1 hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one v1 inference pass (instance segmentation net -> masking -> T-Net ->
+box net) over a batch of synthetic frustums already resident in HBM, followed - on
+N > 1 - by the RCCL all-gather of the per-frustum result records.  Workload:
+BASELINE config 1, 1024 frustums x 1024 points x 4 channels per GPU, fp32 (weak
+scaling: every rank runs the same per-GPU batch).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "3d-object-detection_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+ALGO_GFLOP_PER_FRUSTUM = None   # filled from the layer table below
+
+
+def algorithmic_macs_per_frustum(n, m=512, pc_channels=4):
+    """MACs of the v1 graph with the frustum-constant 1027 inputs of conv6 applied
+    once per frustum instead of once per point (488.5 M at n=1024)."""
+    seg_pt = pc_channels * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * 1024 + 64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2
+    seg_fr = 1027 * 512
+    tnet = (3 * 128 + 128 * 128 + 128 * 256) * m + 259 * 256 + 256 * 128 + 128 * 3
+    box = (3 * 128 + 128 * 128 + 128 * 256 + 256 * 512) * m + 515 * 512 + 512 * 256 + 256 * 59
+    return seg_pt * n + seg_fr + tnet + box
+
+
+class KernelTimer:
+    """HIP-event timer around every shared-MLP launch (events are recorded on the
+    stream the kernels are launched on: torch's current stream)."""
+
+    def __init__(self):
+        self.pending = []
+
+    def begin(self, name, rows, cin, cout):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, 2.0 * rows * cin * cout, e0, e1)
+
+    def end(self, tok):
+        tok[3].record()
+        self.pending.append(tok)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1 in self.pending:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        return agg
+
+
+def cpu_baseline(seconds=12.0):
+    """The numpy restatement of the v1 graph (oracle/v1_numpy.py) timed on this
+    host's cores on BASELINE config 0 batches (32 frustums x 1024 points), repeated
+    for about `seconds` of wall time."""
+    from fpn import plan, synthetic, variables
+    from oracle import v1_numpy as V
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = 1
+    st = variables.VariableStore("cpu", seed=1)
+    plan.init_variables(st, 4, True)
+    st.randomize_batch_norm(2)
+    params = st.numpy()
+    pc, one_hot = synthetic.make_frustums(32, 1024, 4, seed=0)
+    V.get_model(pc, one_hot, params)  # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < seconds:
+        V.get_model(pc, one_hot, params)
+        done += 32
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frustums/s", "cores": int(threads), "kind": "port",
+            "sample": "numpy fp32 restatement of v1 get_model, %d frustums x 1024 pts in batches of 32 (%.1f s)"
+                      % (done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="frustums per GPU")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--chunk", type=int, default=0, help="frustums per chunk (0 = plan default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fpn import dist as fdist
+    from fpn import ops, plan, synthetic, variables
+
+    # identical weights on every rank (seeded); per-rank shard of one global tensor
+    st = variables.VariableStore(dev, seed=1)
+    plan.init_variables(st, 4, True)
+    st.randomize_batch_norm(2)
+    net = plan.V1Plan(st, 4, True, chunk_frustums=args.chunk or None)
+    b_local = args.batch
+    pc_np, oh_np = synthetic.make_frustums(b_local, args.points, 4, seed=rank)
+    pc = torch.from_numpy(pc_np).to(dev)
+    one_hot = torch.from_numpy(oh_np).to(dev)
+    gathered = torch.empty((world * b_local, fdist.RECORD), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        ep = net.forward(pc, one_hot)
+        rec = fdist.pack_results(ep)
+        if world > 1:
+            fdist.gather_results(rec, out=gathered)
+        return rec
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None if args.no_kernel_timer else KernelTimer()
+    ops.launch_observer = timer
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.launch_observer = None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    macs = algorithmic_macs_per_frustum(args.points)
+    total_frustums = world * b_local * args.steps
+    value = total_frustums / dt
+    out = {
+        "metric": "frustums/sec (node) FPointNet v1 N=%d" % args.points,
+        "value": value, "unit": "frustums/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Frustum PointNet v1 inference, %d frustums x %d pts x 4 ch per GPU, fp32 MFMA "
+                               "(BASELINE config 1)" % (b_local, args.points),
+                   "frustums_per_gpu": b_local, "points": args.points,
+                   "algorithmic_gflop_per_frustum": 2 * macs / 1e9,
+                   "model_tflops": value * 2 * macs / 1e12,
+                   "model_frac_of_fp32_mfma_peak": value * 2 * macs / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+                   "parallelism": "frustum-sharded x%d, all_gather of %d-float records" % (world, fdist.RECORD)},
+    }
+    if rank == 0:
+        if timer is not None:
+            agg = timer.summary()
+            name = max(agg, key=lambda k: agg[k][2])
+            launches, flops, secs = agg[name]
+            ach = flops / secs / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": name,
+                               "launches": launches, "avg_launch_ms": secs / launches * 1e3,
+                               "algorithmic_gflop_per_launch": flops / launches / 1e9,
+                               "share_of_step_time": secs / dt}
+            out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3} for k, v in agg.items()}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
