@@ -70,14 +70,14 @@ template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams p)
 {
     constexpr int BN = WN * TN * 32;
-    static_assert(WM * TM * 32 == kBM, "row tile is fixed at 128");
+    constexpr int BM = WM * TM * 32;  // rows per workgroup: 128, or 32 in the small-batch configuration
     static_assert(WM * WN * kWave == kMlpThreads, "4 waves");
-    constexpr int XREG = kBM * kBK / kMlpThreads;  // 16 floats of X per thread per tile
+    constexpr int XREG = BM * kBK / kMlpThreads;  // 16 floats of X per thread per tile
     constexpr int WREG = kBK * BN / kMlpThreads;   // 16 / 8 / 4 floats of W
     constexpr int NQ4 = BN / 4;                    // float4 per W tile row
     constexpr int WROWS = kMlpThreads / NQ4;       // W tile rows per staging pass
 
-    __shared__ float Xs[2][kBM * kXS];
+    __shared__ float Xs[2][BM * kXS];
     __shared__ __attribute__((aligned(16))) float Ws[2][kBK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
     const int l31 = lane & 31, half = lane >> 5;
 
     const int ncb = (p.cout + BN - 1) / BN;
-    const long row0 = (long)(blockIdx.x / ncb) * kBM;
+    const long row0 = (long)(blockIdx.x / ncb) * BM;
     const int col0 = (int)(blockIdx.x % ncb) * BN;
 
     const bool xvec = (p.ldx % 4 == 0) && (p.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
     }
 
     // ---- epilogue ---------------------------------------------------------------
-    float *red = Xs[0];  // (kBM/32, BN) tile maxima; the K loop ended on a barrier
+    float *red = Xs[0];  // (BM/32, BN) tile maxima; the K loop ended on a barrier
     const bool pooled = p.pool_rows > 0;
     const bool gb_tile_uniform = p.group_bias && (p.rows_per_group % 32 == 0);
 #pragma unroll
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
     // either all real rows or all padding
     const int col = col0 + tid;
     if (tid < BN && col < p.cout) {
-        if (p.pool_rows <= kBM) {
+        if (p.pool_rows <= BM) {
             const int tiles_per_group = p.pool_rows / 32;
-            for (int g = 0; g < kBM / p.pool_rows; ++g) {
+            for (int g = 0; g < BM / p.pool_rows; ++g) {
                 const long grow = row0 + (long)g * p.pool_rows;
                 if (grow >= p.rows) break;
                 float m = red[g * tiles_per_group * BN + tid];
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
             }
         } else {
             float m = red[tid];
-            for (int u = 1; u < kBM / 32; ++u) m = fmaxf(m, red[u * BN + tid]);
-            p.partial[(row0 / kBM) * p.cout + col] = m;
+            for (int u = 1; u < BM / 32; ++u) m = fmaxf(m, red[u * BN + tid]);
+            p.partial[(row0 / BM) * p.cout + col] = m;
         }
     }
 }
@@ -361,7 +361,12 @@ template <int MODE>
 int launch_mlp(const MlpParams &p, hipStream_t st)
 {
     const long rb = (p.rows + kBM - 1) / kBM;
-    if (p.cout > 64) {
+    if (p.pool_rows == 0 && p.cout > 64 && rb * ((p.cout + 127) / 128) < 256) {
+        // few rows (the fully connected layers: one row per frustum): 128-row tiles
+        // would leave most of the chip idle, so use 32-row x 128-column tiles
+        const long nblk = ((p.rows + 31) / 32) * ((p.cout + 127) / 128);
+        hipLaunchKernelGGL((shared_mlp_kernel<1, 4, 1, 1, MODE>), dim3((unsigned)nblk), dim3(kMlpThreads), 0, st, p);
+    } else if (p.cout > 64) {
         const long nblk = rb * ((p.cout + 127) / 128);
         FPN_REQUIRE(nblk <= INT32_MAX, "shared_mlp: grid too large");
         hipLaunchKernelGGL((shared_mlp_kernel<2, 2, 2, 2, MODE>), dim3((unsigned)nblk), dim3(kMlpThreads), 0, st, p);

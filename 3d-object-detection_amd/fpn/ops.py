@@ -93,6 +93,57 @@ def max_pool_rows(x, pool_rows, out=None):
     return out
 
 
+def pointer_table(tensors):
+    """Host array of device pointers (the `layers` argument of the chain kernels).
+    The caller keeps `tensors` alive for as long as the table is used."""
+    import ctypes
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def v1_seg_head(pc2d, n, table, point_feat, partial_max):
+    """conv1..conv5 (+ per-128-point maxima) through fpn_v1_seg_head_f32."""
+    rows, cpc = pc2d.shape
+    obs = launch_observer
+    tok = obs.begin("v1_seg_head", rows, 0, 0, macs=rows * (cpc * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024)) \
+        if obs is not None else None
+    with torch.cuda.device(pc2d.device):
+        _lib.check(_lib.load().fpn_v1_seg_head_f32(rows, int(n), cpc, _lib.ptr(pc2d), table, _lib.ptr(point_feat),
+                                                   _lib.ptr(partial_max), _lib.stream_of(pc2d)))
+    if obs is not None:
+        obs.end(tok)
+
+
+def v1_seg_tail(point_feat, n, gbias, table, logits):
+    """conv6..conv10 through fpn_v1_seg_tail_f32."""
+    rows = point_feat.shape[0]
+    obs = launch_observer
+    tok = obs.begin("v1_seg_tail", rows, 0, 0, macs=rows * (64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2)) \
+        if obs is not None else None
+    with torch.cuda.device(point_feat.device):
+        _lib.check(_lib.load().fpn_v1_seg_tail_f32(rows, int(n), _lib.ptr(point_feat), _lib.ptr(gbias), table,
+                                                   _lib.ptr(logits), _lib.stream_of(point_feat)))
+    if obs is not None:
+        obs.end(tok)
+
+
+def v1_obj_chain(obj2d, m, box, delta, table, partial_max):
+    """T-Net (box=False) or box-net (box=True) convolution stack through
+    fpn_v1_obj_chain_f32; `delta` (frustums,3) or None."""
+    rows = obj2d.shape[0]
+    macs = 3 * 128 + 128 * 128 + 128 * 256 + (256 * 512 if box else 0)
+    obs = launch_observer
+    tok = obs.begin("v1_obj_chain_box" if box else "v1_obj_chain_tnet", rows, 0, 0, macs=rows * macs) \
+        if obs is not None else None
+    with torch.cuda.device(obj2d.device):
+        _lib.check(_lib.load().fpn_v1_obj_chain_f32(rows, int(m), int(bool(box)), _lib.ptr(obj2d), _lib.ptr(delta),
+                                                    table, _lib.ptr(partial_max), _lib.stream_of(obj2d)))
+    if obs is not None:
+        obs.end(tok)
+
+
 def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True):
     """point_cloud (B,N,C>=3), logits (B,N,2) -> mask (B,N), mean (B,3), sel
     (B,npick) int32, obj (B,npick,3) through fpn_mask_gather."""

@@ -74,11 +74,12 @@ def init_variables(store, pc_channels=4, bn=True):
 
 
 class V1Plan:
-    def __init__(self, store, pc_channels=4, bn=True, chunk_frustums=None):
+    def __init__(self, store, pc_channels=4, bn=True, chunk_frustums=None, chain=True):
         self.store = store
         self.pc_channels = pc_channels
         self.bn = bn
         self.chunk_frustums = chunk_frustums
+        self.chain = chain      # use the layer-chain kernels for the segmentation net
         init_variables(store, pc_channels, bn)
         self._version = None
         self._prepare()
@@ -93,6 +94,22 @@ class V1Plan:
         w6 = st["conv6/weights"]
         self.w6_pt = w6[:64].contiguous()       # rows of point_feat
         self.w6_glob = w6[64:].contiguous()     # rows of [global_feat | one_hot]
+        # pointer tables of the chain kernels ({w, scale, shift} per layer; a layer
+        # without batch norm gets an explicit scale of ones)
+        def triple(scope, w=None):
+            wt, scale, shift, _ = self.p[scope]
+            if scale is None:
+                scale = torch.ones_like(shift)
+            return [wt if w is None else w, scale, shift]
+        self._head_tensors = sum([triple(s) for s in ("conv1", "conv2", "conv3", "conv4", "conv5")], [])
+        self._tail_tensors = triple("conv6", self.w6_pt) + triple("conv7") + triple("conv8") + triple("conv9") + \
+            [self.p["conv10"][0], self.p["conv10"][2]]
+        self._tnet_tensors = sum([triple(s) for s, _ in TNET_CONV], [])
+        self._box_tensors = sum([triple(s) for s, _ in BOX_CONV], [])
+        self._head_table = ops.pointer_table(self._head_tensors)
+        self._tail_table = ops.pointer_table(self._tail_tensors)
+        self._tnet_table = ops.pointer_table(self._tnet_tensors)
+        self._box_table = ops.pointer_table(self._box_tensors)
         self._version = st.version
 
     def _layer(self, x, scope, **kw):
@@ -104,6 +121,10 @@ class V1Plan:
         # conv7's 256: ~3.6 KB per point with the smaller buffers; a chunk of 1 GiB
         # keeps the launch count low (the layers are compute-bound, so spilling the
         # Infinity Cache costs little) while bounding the transient footprint
+        if self.chain and n % 128 == 0:
+            # the chain kernels keep activations in LDS: per point only point_feat
+            # (256 B), the logits and the mask reach memory
+            return max(1, min(4096, (1 << 30) // (n * 320)))
         per_frustum = n * 3700
         return max(1, min(1024, (1 << 30) // per_frustum))
 
@@ -132,48 +153,70 @@ class V1Plan:
         x = pc.reshape(rows, c)
 
         # --- instance segmentation net (frustum_pointnets_v1.py:20-90) -------------
-        a = self._layer(x, "conv1")
-        a = self._layer(a, "conv2")
-        point_feat = self._layer(a, "conv3")
-        a = self._layer(point_feat, "conv4")
         gcat = torch.empty((b, 1024 + 3), dtype=torch.float32, device=dev)
-        self._layer(a, "conv5", pool_rows=n, out=gcat[:, :1024])      # conv5 + maxpool :57-62
         gcat[:, 1024:] = one_hot                                        # concat one-hot :64
-        del a
-        # frustum-constant part of conv6: [global_feat | one_hot] . W6[64:]
-        gbias = ops.shared_mlp(gcat, self.w6_glob, None, None, relu=False)
-        _, scale6, shift6, _ = self.p["conv6"]
-        a = ops.shared_mlp(point_feat, self.w6_pt, scale6, shift6, relu=True,
-                           group_bias=gbias, rows_per_group=n)          # conv6 :68-71
-        del point_feat
-        a = self._layer(a, "conv7")
-        a = self._layer(a, "conv8")
-        a = self._layer(a, "conv9")
-        logits = self._layer(a, "conv10").reshape(b, n, 2)             # dropout = identity :84-89
-        del a
+        if self.chain and n % 128 == 0:
+            point_feat = torch.empty((rows, 64), dtype=torch.float32, device=dev)
+            partial = torch.empty((rows // 128, 1024), dtype=torch.float32, device=dev)
+            ops.v1_seg_head(x, n, self._head_table, point_feat, partial)          # conv1..conv5 :41-60
+            ops.max_pool_rows(partial, n // 128, out=gcat[:, :1024])              # maxpool :61
+            # frustum-constant part of conv6: [global_feat | one_hot] . W6[64:]
+            gbias = ops.shared_mlp(gcat, self.w6_glob, None, None, relu=False)
+            logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
+            ops.v1_seg_tail(point_feat, n, gbias, self._tail_table, logits)       # conv6..conv10 :68-89
+            del point_feat, partial
+        else:
+            a = self._layer(x, "conv1")
+            a = self._layer(a, "conv2")
+            point_feat = self._layer(a, "conv3")
+            a = self._layer(point_feat, "conv4")
+            self._layer(a, "conv5", pool_rows=n, out=gcat[:, :1024])      # conv5 + maxpool :57-62
+            del a
+            gbias = ops.shared_mlp(gcat, self.w6_glob, None, None, relu=False)
+            _, scale6, shift6, _ = self.p["conv6"]
+            a = ops.shared_mlp(point_feat, self.w6_pt, scale6, shift6, relu=True,
+                               group_bias=gbias, rows_per_group=n)          # conv6 :68-71
+            del point_feat
+            a = self._layer(a, "conv7")
+            a = self._layer(a, "conv8")
+            a = self._layer(a, "conv9")
+            logits = self._layer(a, "conv10").reshape(b, n, 2)             # dropout = identity :84-89
+            del a
 
         # --- masking (model_util.py:275-319) -----------------------------------------
         mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
 
         # --- T-Net (model_util.py:322-357) ---------------------------------------------
-        t = self._layer(obj.reshape(b * m, 3), "conv-reg1-stage1")
-        t = self._layer(t, "conv-reg2-stage1")
         tcat = torch.empty((b, 256 + 3), dtype=torch.float32, device=dev)
-        self._layer(t, "conv-reg3-stage1", pool_rows=m, out=tcat[:, :256])
         tcat[:, 256:] = one_hot
+        obj2d = obj.reshape(b * m, 3)
+        if self.chain:
+            opart = torch.empty((b * m // 64, 512), dtype=torch.float32, device=dev)
+            tpart = opart.view(-1)[:b * m // 64 * 256].view(b * m // 64, 256)
+            ops.v1_obj_chain(obj2d, m, False, None, self._tnet_table, tpart)
+            ops.max_pool_rows(tpart, m // 64, out=tcat[:, :256])
+        else:
+            t = self._layer(obj2d, "conv-reg1-stage1")
+            t = self._layer(t, "conv-reg2-stage1")
+            self._layer(t, "conv-reg3-stage1", pool_rows=m, out=tcat[:, :256])
         t = self._layer(tcat, "fc1-stage1")
         t = self._layer(t, "fc2-stage1")
         center_delta = self._layer(t, "fc3-stage1")
         stage1_center = center_delta + mean                              # frustum_pointnets_v1.py:173
-        obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)     # :176-177
 
         # --- box estimation net (frustum_pointnets_v1.py:93-138) ------------------------
-        t = self._layer(obj_new, "conv-reg1")
-        t = self._layer(t, "conv-reg2")
-        t = self._layer(t, "conv-reg3")
         bcat = torch.empty((b, 512 + 3), dtype=torch.float32, device=dev)
-        self._layer(t, "conv-reg4", pool_rows=m, out=bcat[:, :512])
         bcat[:, 512:] = one_hot
+        if self.chain:
+            # the kernel subtracts center_delta while loading the tile (:176-177)
+            ops.v1_obj_chain(obj2d, m, True, center_delta, self._box_table, opart)
+            ops.max_pool_rows(opart, m // 64, out=bcat[:, :512])
+        else:
+            obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)     # :176-177
+            t = self._layer(obj_new, "conv-reg1")
+            t = self._layer(t, "conv-reg2")
+            t = self._layer(t, "conv-reg3")
+            self._layer(t, "conv-reg4", pool_rows=m, out=bcat[:, :512])
         t = self._layer(bcat, "fc1")
         t = self._layer(t, "fc2")
         output = self._layer(t, "fc3")

@@ -46,11 +46,11 @@ class KernelTimer:
     def __init__(self):
         self.pending = []
 
-    def begin(self, name, rows, cin, cout):
+    def begin(self, name, rows, cin, cout, macs=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        return (name, 2.0 * rows * cin * cout, e0, e1)
+        return (name, 2.0 * (macs if macs is not None else rows * cin * cout), e0, e1)
 
     def end(self, tok):
         tok[3].record()

@@ -189,6 +189,60 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
                                void *stream);
 
 /*
+ * First half of the v1 instance-segmentation net as ONE kernel: conv1..conv5 of
+ * get_instance_seg_v1_net (models/frustum_pointnets_v1.py:41-60) with their
+ * bias/batch-norm/ReLU, plus the per-128-point part of the max-pool at :61.
+ * A workgroup keeps a 128-point tile in LDS through all five layers; only the
+ * point cloud is read and only conv3's output (`point_feat`, :49, needed again by
+ * conv6) and the column maxima are written.
+ *   pc (rows, cpc) with 3 <= cpc <= 8;  rows = frustums * n, n % 128 == 0.
+ *   layers: HOST array of 15 device pointers {w,scale,shift} x {conv1..conv5},
+ *           w row-major (cin,cout), scale/shift as in fpn_shared_mlp_f32 (all non-NULL).
+ *   point_feat (rows,64); partial_max (rows/128, 1024): the maximum of conv5's
+ *   output over each workgroup's 128 points; finish with
+ *   fpn_max_pool_rows(rows/128, 1024, n/128, partial_max, 1024, global_feat, ld).
+ */
+int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,
+                        float *point_feat, float *partial_max, void *stream);
+
+/*
+ * Second half of the same net as ONE kernel: conv6..conv10
+ * (models/frustum_pointnets_v1.py:68-89; dropout :84 is the identity at
+ * inference).  conv6's input is [point_feat | global_feat | one_hot] (:64-66);
+ * the part of the product that is the same for every point of a frustum comes in
+ * as `group_bias` = [global_feat | one_hot] . W6[64:1091] (one row per frustum),
+ * the kernel multiplies only point_feat by W6[0:64].  A workgroup keeps a 64-point
+ * tile in LDS from conv6 to conv10; conv6's 512-wide output is produced in four
+ * 128-column chunks that are consumed by conv7's accumulators at once and never
+ * exist as a whole.
+ *   point_feat (rows,64); group_bias (rows/n, 512); n % 64 == 0.
+ *   layers: HOST array of 14 device pointers {w6[0:64],scale6,shift6, w7,scale7,
+ *           shift7, w8,scale8,shift8, w9,scale9,shift9, w10, bias10} (all non-NULL).
+ *   logits (rows,2).
+ */
+int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_bias,
+                        const float *const *layers, float *logits, void *stream);
+
+/*
+ * Convolution stack over the object points as ONE kernel, 64 points per
+ * workgroup, activations resident in LDS:
+ *   box == 0: T-Net, conv-reg1-stage1..conv-reg3-stage1 (3->128->128->256) of
+ *             get_center_regression_net (models/model_util.py:335-346) and the
+ *             per-64-point part of its max-pool (:347);
+ *   box != 0: box net, conv-reg1..conv-reg4 (3->128->128->256->512) of
+ *             get_3d_box_estimation_v1_net (models/frustum_pointnets_v1.py:108-123)
+ *             and the per-64-point part of its max-pool (:124).
+ * `delta` (rows/m, 3), if not NULL, is subtracted from every point of the frustum
+ * as the tile is loaded: the translation to the T-Net's centre estimate of
+ * frustum_pointnets_v1.py:176-177.
+ *   obj (rows,3), rows = frustums * m, m % 64 == 0.
+ *   layers: HOST array of 9 (T-Net) or 12 (box) device pointers {w,scale,shift}.
+ *   partial_max (rows/64, 256 or 512); finish with fpn_max_pool_rows over m/64 rows.
+ */
+int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
+                         const float *const *layers, float *partial_max, void *stream);
+
+/*
  * Mask, masked centroid and object-point gather of point_cloud_masking +
  * tf_gather_object_pc (models/model_util.py:275-319, :55-86), on the device
  * (the reference leaves the graph for numpy through tf.py_func, :84):

@@ -143,3 +143,17 @@ def test_v1_oracle_fp64_error_budget(device):
     e_gpu = close(ep["mask_logits"].cpu().numpy(), exact["mask_logits"], 1e-3)
     e_cpu = close(cpu32["mask_logits"], exact["mask_logits"], 1e-3)
     assert e_gpu < 1e-4 and e_cpu < 1e-4
+
+
+def test_chain_kernels_match_layer_path(device):
+    """The layer-chain segmentation kernels against the one-layer-per-launch path
+    (same weights, same inputs): logits within the fp32 summation-order band."""
+    from fpn import plan, synthetic
+    st = make_store(device, seed=11)
+    for n in (1024, 2048, 128):
+        pc, one_hot = synthetic.make_frustums(5, n, 4, seed=n)
+        a = plan.V1Plan(st, 4, True, chain=True).forward(dev(pc, device), dev(one_hot, device))
+        b = plan.V1Plan(st, 4, True, chain=False).forward(dev(pc, device), dev(one_hot, device))
+        close(a["mask_logits"].cpu().numpy(), b["mask_logits"].cpu().numpy(), 1e-4)
+        want = V.get_model(pc, one_hot, st.numpy())
+        compare_end_points(a, want, pc, one_hot, st.numpy())
