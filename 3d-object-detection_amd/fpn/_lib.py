@@ -36,6 +36,7 @@ SIGNATURES = {
     "fpn_gather_point": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "fpn_query_ball_point": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "fpn_group_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_three_nn_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1,0 +1,169 @@
+"""PointNet++ layers: counterpart of models/pointnet_util.py (sample_and_group :21,
+sample_and_group_all :58, pointnet_sa_module :86, pointnet_sa_module_msg :155,
+pointnet_fp_module :198), inference mode.
+
+Same signatures and return values; tensors are torch tensors on a ROCm device.
+Inside the modules the work is fused where the reference issues separate ops:
+  * grouping: gather(xyz) - centre, gather(features) and their concatenation are one
+    kernel (fpn_group_concat);
+  * every MLP layer is one call (matmul + bias + batch norm + ReLU), and the max over
+    the nsample axis is fused into the last layer's epilogue;
+  * feature propagation: three_nn, the inverse-distance weights and
+    three_interpolate are one kernel (fpn_three_nn_interpolate).
+Concatenation orders follow the reference exactly: SSG [xyz, features] (:49), MSG
+[features, xyz] (:183), group_all [xyz, features] (:77), FP [interpolated, points1]
+(:218).
+"""
+import torch
+
+from . import _lib, ops, tf_util, variables
+from .tf_ops.tf_grouping import group_point, knn_point, query_ball_point
+from .tf_ops.tf_interpolate import three_nn_interpolate
+from .tf_ops.tf_sampling import farthest_point_sample, gather_point
+
+
+def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
+    """(B,N,3), (B,M,3), (B,N,C) or None, (B,M,ns) -> (B,M,ns,3+C): neighbour
+    coordinates relative to the query joined with neighbour features."""
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    c = 0 if points is None else points.shape[2]
+    out = torch.empty((b, m, ns, 3 + c), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.load().fpn_group_concat(b, n, m, ns, c, int(bool(xyz_first)), _lib.ptr(xyz),
+                                                _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx),
+                                                _lib.ptr(out), _lib.stream_of(xyz)))
+    return out
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
+    """Reference: pointnet_util.py:21-55.  Returns new_xyz (B,npoint,3), new_points
+    (B,npoint,nsample,3+C), idx (B,npoint,nsample), grouped_xyz (B,npoint,nsample,3)."""
+    xyz = xyz.contiguous()
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+    else:
+        idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+    if points is not None and use_xyz:
+        new_points = group_concat(xyz, new_xyz, points.contiguous(), idx, xyz_first=True)
+        grouped_xyz = new_points[..., :3]
+    else:
+        grouped_xyz = group_concat(xyz, new_xyz, None, idx)
+        new_points = grouped_xyz if points is None else group_point(points.contiguous(), idx)
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """Reference: pointnet_util.py:58-83: one group holding every point, centroid (0,0,0),
+    no translation."""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).expand(b, 1, n)
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def _mlp_stack(x2d, widths, scope_fmt, bn, pool_rows=0, out=None):
+    """Shared MLP over the rows of x2d; the pooling over groups of pool_rows rows is
+    fused into the last layer when the kernel supports that group size.  `out`, if
+    given, receives the final result (it may be a column slice of a wider buffer)."""
+    store = variables.get_default_store()
+    fuse_pool = pool_rows and pool_rows % 32 == 0 and (pool_rows <= 128 and 128 % pool_rows == 0 or pool_rows % 128 == 0)
+    for i, cout in enumerate(widths):
+        name = variables.scoped(scope_fmt % i)
+        cin = x2d.shape[1]
+        w = store.get_variable(name + "/weights", (cin, cout), "xavier")
+        store.get_variable(name + "/biases", (cout,), "zeros")
+        if bn:
+            store.get_variable(name + "/bn/gamma", (cout,), "ones")
+            store.get_variable(name + "/bn/beta", (cout,), "zeros")
+            store.get_variable(name + "/bn/moving_mean", (cout,), "zeros")
+            store.get_variable(name + "/bn/moving_variance", (cout,), "ones")
+        scale, shift = store.folded(name, bn)
+        last = i == len(widths) - 1
+        x2d = ops.shared_mlp(x2d, w, scale, shift, relu=True, pool_rows=pool_rows if (last and fuse_pool) else 0,
+                             out=out if (last and (fuse_pool or not pool_rows)) else None)
+    if pool_rows and not fuse_pool:
+        x2d = ops.max_pool_rows(x2d, pool_rows, out=out)
+    return x2d
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay,
+                       scope, bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False):
+    """Set abstraction.  Reference: pointnet_util.py:86-153.  Returns new_xyz
+    (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx (B,npoint,nsample)."""
+    tf_util._inference_only(is_training)
+    with variables.variable_scope(scope):
+        if group_all:
+            nsample = xyz.shape[1]
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+        else:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points,
+                                                                     knn, use_xyz)
+        b, m, ns, c = new_points.shape
+        x2d = new_points.contiguous().reshape(b * m * ns, c)
+        if pooling == 'max':
+            pooled = _mlp_stack(x2d, mlp, 'conv%d', bn, pool_rows=ns)                    # :116-126
+        else:
+            feat = _mlp_stack(x2d, mlp, 'conv%d', bn).reshape(b, m, ns, -1)
+            if pooling == 'avg':
+                pooled = feat.mean(dim=2)
+            elif pooling == 'weighted_avg':                                              # :129-135
+                dists = torch.linalg.vector_norm(grouped_xyz, dim=-1, keepdim=True)
+                exp_dists = torch.exp(-dists * 5)
+                weights = exp_dists / exp_dists.sum(dim=2, keepdim=True)
+                pooled = (feat * weights).sum(dim=2)
+            elif pooling == 'max_and_avg':                                               # :136-139
+                pooled = torch.cat([feat.mean(dim=2), feat.amax(dim=2)], dim=-1)
+            else:
+                raise ValueError("unknown pooling %r" % pooling)
+            pooled = pooled.reshape(b * m, -1).contiguous()
+        if mlp2 is not None:
+            pooled = _mlp_stack(pooled, mlp2, 'conv_post_%d', bn)                        # :142-150
+        return new_xyz, pooled.reshape(b, m, -1), idx
+
+
+def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training, bn_decay,
+                           scope, bn=True, use_xyz=True, use_nchw=False):
+    """Multi-scale-grouping set abstraction.  Reference: pointnet_util.py:155-195.
+    Returns new_xyz (B,npoint,3), new_points (B,npoint,sum of mlp[k][-1])."""
+    tf_util._inference_only(is_training)
+    with variables.variable_scope(scope):
+        xyz = xyz.contiguous()
+        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+        b, m = new_xyz.shape[0], new_xyz.shape[1]
+        width = sum(w[-1] for w in mlp_list)
+        out = torch.empty((b * m, width), dtype=torch.float32, device=xyz.device)
+        col = 0
+        for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
+            idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            if points is not None and use_xyz:
+                grouped = group_concat(xyz, new_xyz, points.contiguous(), idx, xyz_first=False)   # :183
+            elif points is not None:
+                grouped = group_point(points.contiguous(), idx)
+            else:
+                grouped = group_concat(xyz, new_xyz, None, idx)
+            x2d = grouped.reshape(b * m * nsample, grouped.shape[-1])
+            w_i = mlp_list[i][-1]
+            _mlp_stack(x2d, mlp_list[i], 'conv%d_' % i + '%d', bn, pool_rows=nsample,
+                       out=out[:, col:col + w_i])                                                  # :187-194
+            col += w_i
+        return new_xyz, out.reshape(b, m, width)
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
+    """Feature propagation.  Reference: pointnet_util.py:198-228.  xyz1 (B,n,3) dense,
+    xyz2 (B,m,3) sparse, points1 (B,n,c1) or None, points2 (B,m,c2) -> (B,n,mlp[-1])."""
+    tf_util._inference_only(is_training)
+    with variables.variable_scope(scope):
+        interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous())  # :210-215
+        new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated  # :218
+        b, n, c = new_points1.shape
+        y = _mlp_stack(new_points1.reshape(b * n, c).contiguous(), mlp, 'conv_%d', bn)                  # :222-226
+        return y.reshape(b, n, -1)

@@ -84,6 +84,21 @@ int fpn_group_point(int b, int n, int c, int m, int nsample, const float *points
                     const int *idx, float *out, void *stream);
 
 /*
+ * Grouping of a set-abstraction module in one pass:
+ *   xyz_first != 0: out[i,j,k,:] = [xyz[i,t,:] - new_xyz[i,j,:] | points[i,t,:]]
+ *   xyz_first == 0: out[i,j,k,:] = [points[i,t,:] | xyz[i,t,:] - new_xyz[i,j,:]]
+ * with t = idx[i,j,k].  Replaces the group_point(xyz) / subtract / group_point(points)
+ * / concat sequence of sample_and_group (models/pointnet_util.py:44-49, xyz first)
+ * and of pointnet_sa_module_msg (:178-183, features first).  points may be NULL
+ * with c == 0 (output is the relative coordinates only, :53 / :185).
+ *   xyz (b,n,3), new_xyz (b,m,3), points (b,n,c), idx (b,m,nsample) ->
+ *   out (b,m,nsample,3+c).
+ */
+int fpn_group_concat(int b, int n, int m, int nsample, int c, int xyz_first, const float *xyz,
+                     const float *new_xyz, const float *points, const int *idx, float *out,
+                     void *stream);
+
+/*
  * Three nearest neighbours by squared distance, ascending, ties to the lowest
  * index; with m < 3 the missing slots are (+inf, 0).  Replaces threenn_cpu(int b,
  * int n,int m,const float* xyz1,const float* xyz2,float* dist,int* idx),

@@ -1,0 +1,141 @@
+"""GPU parity of the PointNet++ modules and of the v2 topology (BASELINE config 2:
+2048 points, FPS + ball query + group + three_interpolate) against the numpy oracle.
+Indices are compared exactly, features within the 1e-3 scaled bound of
+tests/test_gpu_mlp_v1.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointnet_numpy as P
+from oracle import pointset as O
+from oracle import v1_numpy as V
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def close(got, want, rtol=1e-3):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    s = np.sqrt(np.mean(want ** 2)) + 1e-30
+    err = np.abs(got - want) / np.maximum(np.abs(want), s)
+    assert err.max() <= rtol, "max scaled error %.3e" % err.max()
+
+
+def fresh_store(device, seed=1):
+    from fpn import variables
+    return variables.VariableStore(device, seed=seed)
+
+
+def cloud(b, n, c, seed):
+    rng = np.random.RandomState(seed)
+    xyz = rng.random_sample((b, n, 3)).astype(np.float32)
+    pts = rng.standard_normal((b, n, c)).astype(np.float32) if c else None
+    return xyz, pts
+
+
+def test_group_concat_orders(device):
+    from fpn.pointnet_util import group_concat
+    xyz, pts = cloud(2, 300, 5, 0)
+    new_xyz = xyz[:, :17].copy()
+    idx, _ = O.query_ball_point(0.3, 12, xyz, new_xyz)
+    gx = O.group_point(xyz, idx) - new_xyz[:, :, None, :]
+    gp = O.group_point(pts, idx)
+    got = group_concat(dev(xyz, device), dev(new_xyz, device), dev(pts, device), dev(idx, device), True)
+    np.testing.assert_array_equal(got.cpu().numpy(), np.concatenate([gx, gp], -1))
+    got = group_concat(dev(xyz, device), dev(new_xyz, device), dev(pts, device), dev(idx, device), False)
+    np.testing.assert_array_equal(got.cpu().numpy(), np.concatenate([gp, gx], -1))
+    got = group_concat(dev(xyz, device), dev(new_xyz, device), None, dev(idx, device))
+    np.testing.assert_array_equal(got.cpu().numpy(), gx)
+
+
+def test_sample_and_group(device):
+    from fpn import pointnet_util as U
+    xyz, pts = cloud(2, 512, 6, 1)
+    new_xyz, new_points, idx, grouped_xyz = U.sample_and_group(64, 0.2, 16, dev(xyz, device), dev(pts, device))
+    wx, wp, wi, wg = P.sample_and_group(64, 0.2, 16, xyz, pts)
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx)
+    np.testing.assert_array_equal(new_points.cpu().numpy(), wp)
+    np.testing.assert_array_equal(grouped_xyz.cpu().numpy(), wg)
+    a, b, c, d = U.sample_and_group_all(dev(xyz, device), dev(pts, device))
+    assert a.shape == (2, 1, 3) and (a == 0).all() and b.shape == (2, 1, 512, 9) and c.shape == (2, 1, 512)
+    np.testing.assert_array_equal(b[:, 0, :, :3].cpu().numpy(), xyz)
+    # knn grouping goes through select_top_k
+    _, kp, kidx, _ = U.sample_and_group(8, None, 4, dev(xyz, device), dev(pts, device), knn=True)
+    assert kp.shape == (2, 8, 4, 9) and kidx.shape == (2, 8, 4)
+
+
+@pytest.mark.parametrize("pooling", ["max", "avg", "max_and_avg", "weighted_avg"])
+def test_sa_module(device, pooling):
+    from fpn import pointnet_util as U
+    from fpn import variables
+    xyz, pts = cloud(2, 512, 6, 2)
+    st = fresh_store(device)
+    with variables.use_store(st):
+        new_xyz, feat, idx = U.pointnet_sa_module(dev(xyz, device), dev(pts, device), 64, 0.25, 32, [32, 48], None,
+                                                  False, False, None, scope='sa', pooling=pooling)
+    st.randomize_batch_norm(3)
+    with variables.use_store(st):
+        new_xyz, feat, idx = U.pointnet_sa_module(dev(xyz, device), dev(pts, device), 64, 0.25, 32, [32, 48], None,
+                                                  False, False, None, scope='sa', pooling=pooling)
+    assert feat.shape == (2, 64, 96 if pooling == "max_and_avg" else 48)
+    if pooling == "max":
+        wx, wf = P.sa_module(xyz, pts, 64, 0.25, 32, [32, 48], False, st.numpy(), "sa")
+        np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx)
+        close(feat.cpu().numpy(), wf)
+
+
+def test_sa_msg_and_fp_modules(device):
+    from fpn import pointnet_util as U
+    from fpn import variables
+    xyz, pts = cloud(2, 1024, 1, 4)
+    st = fresh_store(device)
+    args = (64, [0.1, 0.2, 0.4], [32, 64, 128], [[16, 32], [32, 32], [32, 64]])
+    for rnd in (0, 1):
+        with variables.use_store(st):
+            new_xyz, feat = U.pointnet_sa_module_msg(dev(xyz, device), dev(pts, device), *args, False, None, scope='m')
+            up = U.pointnet_fp_module(dev(xyz, device), new_xyz, dev(pts, device), feat, [64, 32], False, None,
+                                      scope='fp')
+        if rnd == 0:
+            st.randomize_batch_norm(5)
+    wx, wf = P.sa_module_msg(xyz, pts, *args, st.numpy(), "m")
+    np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx)
+    close(feat.cpu().numpy(), wf)
+    wu = P.fp_module(xyz, wx, pts, wf, [64, 32], st.numpy(), "fp")
+    assert up.shape == (2, 1024, 32)
+    close(up.cpu().numpy(), wu)
+
+
+def test_v2_get_model_config2(device):
+    """BASELINE config 2: v2 topology on 2048-point frustums."""
+    from fpn import synthetic, variables
+    from fpn.models import frustum_pointnets_v2 as M2
+    pc, one_hot = synthetic.make_frustums(3, 2048, 4, seed=2)
+    pc[..., :3] *= 0.05      # bring the metric frustum into the radius range of the SA modules
+    st = fresh_store(device, seed=7)
+    with variables.use_store(st):
+        M2.get_model(dev(pc, device), dev(one_hot, device), False)      # creates the variables
+    st.randomize_batch_norm(8)
+    with variables.use_store(st):
+        ep = M2.get_model(dev(pc, device), dev(one_hot, device), False)
+    params = st.numpy()
+    logits = P.v2_instance_seg(pc, one_hot, params, M2.CONFIG)
+    close(ep["mask_logits"].cpu().numpy(), logits)
+    mask = ep["mask"].cpu().numpy()
+    obj, mean, _, idx = V.point_cloud_masking(pc, logits, mask_override=mask)
+    np.testing.assert_array_equal(ep["object_point_indices"].cpu().numpy(), idx)
+    delta = V.center_regression_net(obj, one_hot, params)
+    close(ep["center_delta"].cpu().numpy(), delta)
+    # the box net's own FPS runs on (obj - delta); feed the oracle the GPU's delta so that
+    # rounding differences in delta cannot change the sampled set
+    gdelta = ep["center_delta"].cpu().numpy()
+    out = P.v2_box_estimation(obj - gdelta[:, None, :], one_hot, params, M2.CONFIG)
+    close(ep["box_output"].cpu().numpy(), out)
+    assert ep["center"].shape == (3, 3) and ep["size_residuals"].shape == (3, 8, 3)
