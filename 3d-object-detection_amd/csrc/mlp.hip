@@ -454,9 +454,9 @@ int fpn_shared_mlp_f32(long rows, int cin, int cout, const float *x, int ldx, co
 
 int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w_mean,
                                const float *w_delta, long rows_per_sample, const float *sign_in,
-                               const float *sign_out, int rows_per_group, const float *scale,
-                               const float *shift, int relu, int pool_rows, float *y, int ldy,
-                               void *workspace, size_t workspace_bytes, void *stream)
+                               const float *sign_out, int rows_per_group, const float *group_bias,
+                               const float *scale, const float *shift, int relu, int pool_rows, float *y,
+                               int ldy, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_common("shared_mlp_flipout", rows, cin, cout, x, ldx, w_mean, pool_rows, y, ldy, workspace, workspace_bytes);
     if (rc != FPN_OK) return rc;
@@ -478,7 +478,8 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
         p.w = w_mean; p.w_delta = w_delta + s * (long)cin * cout;
         p.sign_in = sign_in + s * groups_per_sample * cin;
         p.sign_out = sign_out + s * groups_per_sample * cout;
-        p.scale = scale; p.shift = shift; p.group_bias = nullptr; p.rows_per_group = rows_per_group;
+        p.scale = scale; p.shift = shift; p.rows_per_group = rows_per_group;
+        p.group_bias = group_bias ? group_bias + s * groups_per_sample * cout : nullptr;
         p.relu = relu; p.pool_rows = pool_rows; p.ldy = ldy;
         p.y = y + (pool_rows ? (s * rows_per_sample / pool_rows) : s * rows_per_sample) * (long)ldy;
         const size_t ws_per_sample = fpn_shared_mlp_workspace_bytes(rows_per_sample, cout, pool_rows);

@@ -42,12 +42,13 @@ SIGNATURES = {
     "fpn_three_nn_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_select_top_k": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fpn_shared_mlp_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
-    "fpn_shared_mlp_flipout_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _i, _i,
+    "fpn_shared_mlp_flipout_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
                                    _vp, _i, _vp, _sz, _vp],
     "fpn_max_pool_rows": [_l, _i, _i, _vp, _i, _vp, _i, _vp],
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_mask_gather": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 

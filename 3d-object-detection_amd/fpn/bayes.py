@@ -1,0 +1,182 @@
+"""Flipout (Bayesian) execution of the v1 topology: the network of
+models/FPointNet_Bayes.py:71-223.
+
+Layer kinds (FPointNet_Bayes.py:54-68,93,115,136):
+  * every convolution, including the 2-channel segmentation head, is a
+    tfp.layers.Convolution2DFlipout(filters, 1, 1, "valid") (+ ReLU except the head);
+  * the hidden fully connected layers are tfp.layers.DenseFlipout + ReLU;
+  * the two output layers (Dense(59), Dense(3)) are deterministic;
+  * no batch norm; Dropout(0.5) before the segmentation head is the identity in
+    `predict` (Keras inference mode) and can be switched on as Monte-Carlo dropout.
+
+Flipout arithmetic (the tfp layers are not part of the reference tree; this is the
+published estimator, Wen et al. 2018, as tfp implements it):
+    y = x . W_mean + b + ((x * s_in) . dW) * s_out,     dW = softplus(rho) * eps
+with ONE eps ~ N(0,1) draw per forward call shared by the batch, and independent
+Rademacher sign vectors s_in (cin), s_out (cout) per example.  One forward call = one
+Monte-Carlo sample; S samples are S calls with fresh noise.
+
+Variables per Flipout layer: '<scope>/weights' (posterior mean, tfp
+kernel_posterior_loc), '<scope>/rho' (tfp kernel_posterior_untransformed_scale),
+'<scope>/biases' (bias_posterior_loc, deterministic in tfp's default).
+"""
+import numpy as np
+import torch
+
+from . import model_util, ops, plan as _plan
+
+FLIPOUT_EPS = float(np.finfo(np.float32).eps)   # tfp adds eps to softplus(rho)
+
+# scopes of the deterministic output layers
+PLAIN = ("fc3-stage1", "fc3")
+
+
+def init_variables(store, pc_channels=3, rho_mean=-3.0, rho_std=0.1, seed=3):
+    """Weights of the v1 topology without batch norm plus a 'rho' per Flipout layer
+    (N(rho_mean, rho_std), tfp's default untransformed-scale initialiser)."""
+    _plan.init_variables(store, pc_channels, bn=False)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+    for scope, cin, cout, _, _ in _plan.layer_table(pc_channels):
+        if scope in PLAIN or (scope + "/rho") in store:
+            continue
+        store[scope + "/rho"] = torch.randn((cin, cout), generator=g) * rho_std + rho_mean
+    return store
+
+
+class BayesPlan:
+    """S Monte-Carlo forward passes of the Flipout network."""
+
+    def __init__(self, store, pc_channels=3, chunk_frustums=None, mc_dropout=False):
+        self.store = store
+        self.pc_channels = pc_channels
+        self.chunk_frustums = chunk_frustums
+        self.mc_dropout = mc_dropout
+        init_variables(store, pc_channels)
+        self.table = _plan.layer_table(pc_channels)
+
+    # ---- noise -------------------------------------------------------------
+    def sample_noise(self, nsamples, batch, generator=None):
+        """All randomness of `nsamples` forward passes over `batch` frustums:
+        noise[scope] = (eps (S,cin,cout), sign_in (S,batch,cin), sign_out (S,batch,cout))."""
+        dev = self.store.device
+        noise = {}
+        for scope, cin, cout, _, _ in self.table:
+            if scope in PLAIN:
+                continue
+            eps = torch.randn((nsamples, cin, cout), device=dev, generator=generator)
+            si = torch.randint(0, 2, (nsamples, batch, cin), device=dev, generator=generator).float() * 2 - 1
+            so = torch.randint(0, 2, (nsamples, batch, cout), device=dev, generator=generator).float() * 2 - 1
+            noise[scope] = (eps, si, so)
+        if self.mc_dropout:
+            noise["dropout"] = None   # drawn per chunk (one mask element per activation)
+        return noise
+
+    def _sigma(self, scope):
+        return torch.nn.functional.softplus(self.store[scope + "/rho"]) + FLIPOUT_EPS
+
+    # ---- layers --------------------------------------------------------------
+    def _flip(self, x, scope, dw, si, so, rows_per_group, relu=True, pool_rows=0, out=None):
+        """One Flipout layer on the rows of x; dw (cin,cout), si (groups,cin), so
+        (groups,cout)."""
+        return ops.shared_mlp_flipout(x, self.store[scope + "/weights"], dw.reshape(1, *dw.shape), x.shape[0],
+                                      si, so, rows_per_group, scale=None, shift=self.store[scope + "/biases"],
+                                      relu=relu, pool_rows=pool_rows, out=out)
+
+    def _plain(self, x, scope):
+        return ops.shared_mlp(x, self.store[scope + "/weights"], None, self.store[scope + "/biases"], relu=False)
+
+    def default_chunk(self, n):
+        return max(1, min(1024, (1 << 30) // (n * 3700)))
+
+    def forward(self, point_cloud, one_hot_vec, nsamples=1, noise=None, generator=None):
+        """-> dict of tensors with a leading sample axis: mask_logits (S,B,N,2),
+        box_output (S,B,59), stage1_center (S,B,3), center (S,B,3), mask (S,B,N), ..."""
+        b, n, c = point_cloud.shape
+        if n % 32 != 0:
+            raise ValueError("the fused max-pool needs the number of points per frustum to be a multiple of 32")
+        if noise is None:
+            noise = self.sample_noise(nsamples, b, generator)
+        chunk = self.chunk_frustums or self.default_chunk(n)
+        per_sample = []
+        for s in range(nsamples):
+            dws = {k: self._sigma(k) * v[0][s] for k, v in noise.items() if v is not None}
+            outs = []
+            for lo in range(0, b, chunk):
+                hi = min(b, lo + chunk)
+                sl = {k: (dws[k], v[1][s, lo:hi].contiguous(), v[2][s, lo:hi].contiguous())
+                      for k, v in noise.items() if v is not None}
+                outs.append(self._forward_chunk(point_cloud[lo:hi], one_hot_vec[lo:hi], sl, generator))
+            per_sample.append({k: torch.cat([o[k] for o in outs], 0) if len(outs) > 1 else outs[0][k]
+                               for k in outs[0]})
+        return {k: torch.stack([p[k] for p in per_sample], 0) for k in per_sample[0]}
+
+    def _forward_chunk(self, pc, one_hot, nz, generator):
+        b, n, c = pc.shape
+        dev = pc.device
+        m = model_util.NUM_OBJECT_POINT
+        x = pc.reshape(b * n, c)
+
+        def conv(x, scope, rpg, **kw):
+            dw, si, so = nz[scope]
+            return self._flip(x, scope, dw, si, so, rpg, **kw)
+
+        # segmentation net (FPointNet_Bayes.py:71-96)
+        a = conv(x, "conv1", n)
+        a = conv(a, "conv2", n)
+        point_feat = conv(a, "conv3", n)
+        a = conv(point_feat, "conv4", n)
+        gcat = torch.empty((b, 1024 + 3), dtype=torch.float32, device=dev)
+        conv(a, "conv5", n, pool_rows=n, out=gcat[:, :1024])
+        gcat[:, 1024:] = one_hot
+        del a
+        # conv6 on [point_feat | global_feat | one_hot]: the frustum-constant 1027
+        # inputs are multiplied once per frustum (one Flipout product on B rows with
+        # per-row signs) and enter the per-point product as a per-frustum bias
+        dw6, si6, so6 = nz["conv6"]
+        w6 = self.store["conv6/weights"]
+        gbias = ops.shared_mlp_flipout(gcat, w6[64:].contiguous(), dw6[64:].reshape(1, 1027, 512).contiguous(),
+                                       b, si6[:, 64:].contiguous(), so6, 1, scale=None, shift=None, relu=False)
+        a = ops.shared_mlp_flipout(point_feat, w6[:64].contiguous(), dw6[:64].reshape(1, 64, 512).contiguous(),
+                                   b * n, si6[:, :64].contiguous(), so6, n, scale=None,
+                                   shift=self.store["conv6/biases"], relu=True, group_bias=gbias)
+        del point_feat
+        a = conv(a, "conv7", n)
+        a = conv(a, "conv8", n)
+        a = conv(a, "conv9", n)
+        if self.mc_dropout:   # layers.Dropout(rate=0.5), active (FPointNet_Bayes.py:92)
+            keep = torch.rand(a.shape, device=dev, generator=generator) >= 0.5
+            a = a * keep * 2.0
+        logits = conv(a, "conv10", n, relu=False).reshape(b, n, 2)
+        del a
+
+        mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
+
+        # T-Net (FPointNet_Bayes.py:120-137)
+        t = conv(obj.reshape(b * m, 3), "conv-reg1-stage1", m)
+        t = conv(t, "conv-reg2-stage1", m)
+        tcat = torch.empty((b, 256 + 3), dtype=torch.float32, device=dev)
+        conv(t, "conv-reg3-stage1", m, pool_rows=m, out=tcat[:, :256])
+        tcat[:, 256:] = one_hot
+        t = conv(tcat, "fc1-stage1", 1)
+        t = conv(t, "fc2-stage1", 1)
+        center_delta = self._plain(t, "fc3-stage1")
+        stage1_center = center_delta + mean
+        obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)
+
+        # box net (FPointNet_Bayes.py:99-117)
+        t = conv(obj_new, "conv-reg1", m)
+        t = conv(t, "conv-reg2", m)
+        t = conv(t, "conv-reg3", m)
+        bcat = torch.empty((b, 512 + 3), dtype=torch.float32, device=dev)
+        conv(t, "conv-reg4", m, pool_rows=m, out=bcat[:, :512])
+        bcat[:, 512:] = one_hot
+        t = conv(bcat, "fc1", 1)
+        t = conv(t, "fc2", 1)
+        output = self._plain(t, "fc3")
+
+        ep = {"mask_logits": logits, "mask": mask, "object_point_indices": sel, "mask_xyz_mean": mean,
+              "center_delta": center_delta, "stage1_center": stage1_center, "box_output": output}
+        model_util.parse_output_to_tensors(output, ep)
+        ep["center"] = ep["center_boxnet"] + stage1_center
+        return ep

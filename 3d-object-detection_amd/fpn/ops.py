@@ -55,7 +55,7 @@ def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=
 
 
 def shared_mlp_flipout(x, w_mean, w_delta, rows_per_sample, sign_in, sign_out, rows_per_group,
-                       scale=None, shift=None, relu=True, pool_rows=0, out=None):
+                       scale=None, shift=None, relu=True, pool_rows=0, out=None, group_bias=None):
     """Flipout layer through fpn_shared_mlp_flipout_f32: x (S*rows_per_sample, cin),
     w_mean (cin,cout), w_delta (S,cin,cout), sign_in (groups,cin), sign_out
     (groups,cout) with groups = rows / rows_per_group."""
@@ -73,7 +73,8 @@ def shared_mlp_flipout(x, w_mean, w_delta, rows_per_sample, sign_in, sign_out, r
     with torch.cuda.device(x.device):
         _lib.check(lib.fpn_shared_mlp_flipout_f32(
             rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(w_mean), _lib.ptr(w_delta), int(rows_per_sample),
-            _lib.ptr(sign_in), _lib.ptr(sign_out), int(rows_per_group), _lib.ptr(scale), _lib.ptr(shift),
+            _lib.ptr(sign_in), _lib.ptr(sign_out), int(rows_per_group), _lib.ptr(group_bias),
+            _lib.ptr(scale), _lib.ptr(shift),
             int(bool(relu)), int(pool_rows), _lib.ptr(out), ldy, _lib.ptr(ws), ws_bytes,
             _lib.stream_of(x)))
     return out

@@ -191,17 +191,21 @@ int fpn_max_pool_rows(long rows, int c, int pool_rows, const float *x, int ldx, 
  *     acc = x . w_mean + ((x * sign_in[g]) . w_delta[s]) * sign_out[g]
  * with g = r / rows_per_group (one sign pair per example) and s =
  * r / rows_per_sample (one weight perturbation per Monte-Carlo sample, so S
- * samples are batched as S*rows_per_sample rows of one launch); then the same
- * scale/shift/relu/pool epilogue as fpn_shared_mlp_f32.
+ * samples are batched as S*rows_per_sample rows of one call); group_bias
+ * (rows/rows_per_group, cout), if not NULL, is added to acc; then the same
+ * scale/shift/relu/pool epilogue as fpn_shared_mlp_f32.  When rows_per_group is a
+ * multiple of 128 the perturbation is folded into the weight tile
+ * (w_mean + sign_in^T * w_delta * sign_out, exact because the signs are +-1) and the
+ * layer costs ONE product instead of the two of the textbook form.
  *   w_delta (nsamples, cin, cout); sign_in (rows/rows_per_group, cin) and
  *   sign_out (rows/rows_per_group, cout) hold +1/-1 as f32.
  */
 int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int ldx,
                                const float *w_mean, const float *w_delta, long rows_per_sample,
                                const float *sign_in, const float *sign_out, int rows_per_group,
-                               const float *scale, const float *shift, int relu, int pool_rows,
-                               float *y, int ldy, void *workspace, size_t workspace_bytes,
-                               void *stream);
+                               const float *group_bias, const float *scale, const float *shift,
+                               int relu, int pool_rows, float *y, int ldy, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /*
  * First half of the v1 instance-segmentation net as ONE kernel: conv1..conv5 of
@@ -278,6 +282,25 @@ int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const floa
 int fpn_mask_gather(int b, int n, int cpc, int npick, const float *point_cloud,
                     const float *logits, float *mask, float *mean, int *sel, float *obj,
                     void *stream);
+
+/*
+ * Monte-Carlo ensemble statistics over S sampled forward passes of the Bayesian
+ * detector (the reference produces the samples with repeated `predict` calls of
+ * models/FPointNet_Bayes.py's det_model and holds no code for the statistics; the
+ * definitions are those of its project report, section 3: Shannon entropy of the
+ * sample-mean class probabilities and total variance = trace of
+ * C = 1/S sum v v^T - mean mean^T, eq. 8).
+ *   box_output (s,b,59), stage1_center (s,b,3) -> stats (b,30):
+ *     [0:7]   mean detection v = (cx,cy,cz, l,w,h, heading); per sample the centre is
+ *             center_boxnet + stage1_center, the size is the mean size of the arg-max
+ *             size cluster plus its residual, the heading is the centre of the
+ *             arg-max heading bin plus its residual
+ *     [7]     total variance of v
+ *     [8],[9] entropy of the mean heading-bin / size-cluster probabilities (nats)
+ *     [10:22] mean heading-bin probabilities, [22:30] mean size-cluster probabilities
+ */
+int fpn_mc_statistics(int s, int b, const float *box_output, const float *stage1_center,
+                      float *stats, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,184 @@
+"""GPU parity of the Flipout path, the Keras-style variant, the ensemble statistics
+and the test.py post-processing.
+
+Flipout: PARITY UNPINNED by the reference (the arithmetic is tensorflow_probability's,
+absent here).  Pinned instead: (i) identical noise -> the HIP path (folded single
+product for convolutions, two-pass for dense layers) equals the textbook two-product
+formula evaluated in float64 within 1e-3 scaled error; (ii) zero perturbation ->
+equals the deterministic network; (iii) the output moments over many draws match the
+analytic Flipout moments; (iv) a seeded generator reproduces its draws."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bayes_numpy as BN
+from oracle import v1_numpy as V
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def close(got, want, rtol=1e-3):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    s = np.sqrt(np.mean(want ** 2)) + 1e-30
+    err = np.abs(got - want) / np.maximum(np.abs(want), s)
+    assert err.max() <= rtol, "max scaled error %.3e" % err.max()
+
+
+def test_flipout_layer_fold_and_two_pass(device):
+    from fpn import ops
+    rng = np.random.RandomState(0)
+    for (groups, rpg, cin, cout, pool) in [(3, 128, 64, 96, 0), (2, 256, 20, 130, 128), (37, 1, 259, 64, 0),
+                                           (4, 32, 16, 40, 32)]:
+        S = 2
+        rows = groups * rpg
+        x = rng.standard_normal((S * rows, cin)).astype(np.float32)
+        w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        dw = (rng.standard_normal((S, cin, cout)) * 0.05).astype(np.float32)
+        si = rng.choice([-1.0, 1.0], (S * groups, cin)).astype(np.float32)
+        so = rng.choice([-1.0, 1.0], (S * groups, cout)).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32)
+        got = ops.shared_mlp_flipout(dev(x, device), dev(w, device), dev(dw, device), rows, dev(si, device),
+                                     dev(so, device), rpg, shift=dev(bias, device), relu=True, pool_rows=pool)
+        want = []
+        for s in range(S):
+            xs = x[s * rows:(s + 1) * rows].astype(np.float64)
+            sis = np.repeat(si[s * groups:(s + 1) * groups], rpg, 0)
+            sos = np.repeat(so[s * groups:(s + 1) * groups], rpg, 0)
+            y = np.maximum(xs @ w + bias + ((xs * sis) @ dw[s].astype(np.float64)) * sos, 0)
+            want.append(y.reshape(-1, pool, cout).max(1) if pool else y)
+        close(got.cpu().numpy(), np.concatenate(want, 0), 1e-4)
+
+
+def bayes_setup(device, B=4, N=256, seed=0):
+    from fpn import bayes, synthetic, variables
+    st = variables.VariableStore(device, seed=seed + 1)
+    bp = bayes.BayesPlan(st, 3)
+    for k in list(st.keys()):
+        if k.endswith("/biases"):
+            st[k] = torch.randn(st[k].shape) * 0.1
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=seed)
+    return st, bp, pc, oh
+
+
+def test_bayes_forward_matches_textbook_flipout(device):
+    st, bp, pc, oh = bayes_setup(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    S = 2
+    noise = bp.sample_noise(S, pc.shape[0], g)
+    ep = bp.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+    params = st.numpy()
+    for s in range(S):
+        nz = {k: ((torch.nn.functional.softplus(st[k + "/rho"]) + np.finfo(np.float32).eps) * v[0][s]).cpu().numpy()
+              for k, v in noise.items()}
+        nz = {k: (nz[k], noise[k][1][s].cpu().numpy(), noise[k][2][s].cpu().numpy()) for k in nz}
+        want = BN.forward_sample(pc, oh, params, nz)
+        close(ep["mask_logits"][s].cpu().numpy(), want["mask_logits"])
+        mask = ep["mask"][s].cpu().numpy()
+        if not np.array_equal(mask, want["mask"]):
+            want = BN.forward_sample(pc, oh, params, nz, mask_override=mask)
+        np.testing.assert_array_equal(ep["object_point_indices"][s].cpu().numpy(), want["object_point_indices"])
+        for k in ("center_delta", "stage1_center", "box_output", "center", "size_residuals"):
+            close(ep[k][s].cpu().numpy(), want[k])
+    # different samples really differ, and a re-seeded generator reproduces them
+    assert not torch.equal(ep["box_output"][0], ep["box_output"][1])
+    g.manual_seed(5)
+    ep2 = bp.forward(dev(pc, device), dev(oh, device), S, generator=g)
+    assert torch.equal(ep["box_output"], ep2["box_output"])
+
+
+def test_bayes_zero_perturbation_equals_deterministic(device):
+    from fpn import plan
+    st, bp, pc, oh = bayes_setup(device, seed=3)
+    noise = bp.sample_noise(1, pc.shape[0])
+    noise = {k: (torch.zeros_like(v[0]), v[1], v[2]) for k, v in noise.items()}
+    ep = bp.forward(dev(pc, device), dev(oh, device), 1, noise=noise)
+    det = plan.V1Plan(st, 3, bn=False, chain=False).forward(dev(pc, device), dev(oh, device))
+    close(ep["mask_logits"][0].cpu().numpy(), det["mask_logits"].cpu().numpy(), 1e-4)
+    want = V.get_model(pc, oh, st.numpy(), bn=False)
+    close(det["mask_logits"].cpu().numpy(), want["mask_logits"])
+
+
+def test_flipout_moments(device):
+    """E[y] = x.W + b and Var[y_j] = sum_k x_k^2 sigma_kj^2 for independent draws."""
+    from fpn import ops
+    rng = np.random.RandomState(2)
+    cin, cout, rows, S = 24, 16, 128, 4000
+    x1 = rng.standard_normal((1, cin)).astype(np.float32)
+    x = np.repeat(x1, rows, 0)
+    w = rng.standard_normal((cin, cout)).astype(np.float32)
+    sigma = rng.uniform(0.05, 0.2, (cin, cout)).astype(np.float32)
+    g = torch.Generator(device=device)
+    g.manual_seed(9)
+    eps = torch.randn((S, cin, cout), device=device, generator=g)
+    si = torch.randint(0, 2, (S, cin), device=device, generator=g).float() * 2 - 1
+    so = torch.randint(0, 2, (S, cout), device=device, generator=g).float() * 2 - 1
+    xs = dev(x, device).repeat(S, 1)
+    y = ops.shared_mlp_flipout(xs, dev(w, device), (dev(sigma, device) * eps).contiguous(), rows, si, so, rows,
+                               relu=False).reshape(S, rows, cout)[:, 0]
+    mean = y.mean(0).cpu().numpy()
+    var = y.var(0).cpu().numpy()
+    want_mean = x1[0].astype(np.float64) @ w
+    want_var = (x1[0].astype(np.float64) ** 2) @ (sigma.astype(np.float64) ** 2)
+    assert np.abs(mean - want_mean).max() < 5 * np.sqrt(want_var.max() / S)
+    np.testing.assert_allclose(var, want_var, rtol=0.15)
+
+
+def test_mc_statistics(device):
+    from fpn import uncertainty
+    rng = np.random.RandomState(4)
+    S, B = 32, 50
+    box = rng.standard_normal((S, B, 59)).astype(np.float32)
+    box[..., :3] += 30.0
+    c1 = (rng.standard_normal((S, B, 3)) * 0.01 + 20).astype(np.float32)
+    stats = uncertainty.mc_statistics(dev(box, device), dev(c1, device))
+    got = {k: v.cpu().numpy() for k, v in uncertainty.unpack(stats).items()}
+    want = BN.mc_statistics(box, c1)
+    for k in want:
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    # identical samples: zero variance, entropy of a single softmax
+    same = np.repeat(box[:1], S, 0)
+    st2 = uncertainty.unpack(uncertainty.mc_statistics(dev(same, device), dev(np.repeat(c1[:1], S, 0), device)))
+    assert float(st2["total_variance"].abs().max()) < 1e-6
+
+
+def test_keras_and_bayes_model_surfaces(device):
+    from fpn import inference, synthetic, variables
+    from fpn.models import FPointNet_Bayes, FPointNet_Keras, frustum_pointnet
+    pc, oh = synthetic.make_frustums(4, 1024, 3, seed=1)
+    st = variables.VariableStore(device, seed=2)
+    with variables.use_store(st):
+        train, det = FPointNet_Keras.Frustum_Pointnet_Model(batch_size=4)
+        outs = det.predict({"frustum_point_cloud": pc, "one_hot_vec": oh})
+        ep = FPointNet_Keras.get_model(dev(pc, device), dev(oh, device), False)
+    assert [o.shape for o in outs] == [(4, 1024, 2), (4, 3), (4, 12), (4, 12), (4, 8), (4, 8, 3)]
+    want = V.get_model(pc, oh, st.numpy(), bn=False)
+    close(outs[0], want["mask_logits"])
+    if np.array_equal(ep["mask"].cpu().numpy(), want["mask"]):
+        close(outs[1], want["center"])
+        close(outs[5], want["size_residuals"])
+    with pytest.raises(NotImplementedError):
+        train.fit(None)
+    # test.py:inference post-processing on the det outputs
+    got = inference.postprocess(*outs)
+    ref = V.inference_postprocess(*outs)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    assert got[0].shape == (4, 1024) and got[6].shape == (4,)
+
+    st2 = variables.VariableStore(device, seed=3)
+    with variables.use_store(st2):
+        _, bdet = FPointNet_Bayes.Frustum_Pointnet_Model(batch_size=4)
+        o1 = bdet.predict([pc, oh])
+        o2 = bdet.predict([pc, oh])
+        ep = FPointNet_Bayes.get_model(dev(pc, device), dev(oh, device), False, nsamples=3)
+        _, d11 = frustum_pointnet.frustum_pointnet()
+        o11 = d11.predict([pc, oh])
+    assert len(o1) == 6 and not np.array_equal(o1[0], o2[0])       # every predict draws fresh weights
+    assert ep["box_output"].shape == (3, 4, 59) and ep["mc_statistics"].shape == (4, 30)
+    assert len(o11) == 11 and o11[1].shape == (4, 1024)
