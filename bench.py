@@ -95,6 +95,49 @@ def cpu_baseline(seconds=12.0):
                       % (done, dt)}
 
 
+PEAK_HBM_GBS = 8000.0   # MI355X HBM3E spec peak, GB/s
+
+
+def pointset_ops(dev, frustums=256, reps=20):
+    """Achieved HBM GB/s of the point-set operators at the v2 shapes (2048 points per
+    frustum, 128 FPS samples), from the ALGORITHMIC bytes of each operator (inputs read
+    once + outputs written once) and HIP-event time on the launch stream."""
+    from fpn import synthetic
+    from fpn.tf_ops import tf_grouping, tf_interpolate, tf_sampling
+    B, N, M, NS, C = frustums, 2048, 128, 64, 64
+    xyz = torch.from_numpy(synthetic.unit_cube(B, N)).to(dev)
+    feat = torch.randn((B, N, C), device=dev)
+    idx = tf_sampling.farthest_point_sample(M, xyz)
+    new_xyz = tf_sampling.gather_point(xyz, idx)
+    gi, _ = tf_grouping.query_ball_point(0.4, NS, xyz, new_xyz)
+    feat2 = torch.randn((B, M, C), device=dev)
+    cases = {
+        "farthest_point_sample(2048->128)": (lambda: tf_sampling.farthest_point_sample(M, xyz), 12 * N + 4 * M),
+        "gather_point(128)": (lambda: tf_sampling.gather_point(xyz, idx), 4 * M + 24 * M),
+        "query_ball_point(2048,128,r0.4,ns64)": (lambda: tf_grouping.query_ball_point(0.4, NS, xyz, new_xyz),
+                                                 12 * (N + M) + 4 * M * NS + 4 * M),
+        "group_point(c=64)": (lambda: tf_grouping.group_point(feat, gi), 4 * M * NS + 2 * 4 * M * NS * C),
+        "three_nn(2048,128)": (lambda: tf_interpolate.three_nn(xyz, new_xyz), 12 * (N + M) + 24 * N),
+        "three_nn_interpolate(2048,128,c=64)": (lambda: tf_interpolate.three_nn_interpolate(xyz, new_xyz, feat2),
+                                                12 * (N + M) + 4 * M * C + 4 * N * C),
+    }
+    out = {}
+    for name, (fn, bytes_per_frustum) in cases.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = B * bytes_per_frustum / ms / 1e6
+        out[name] = {"ms": ms, "frustums_per_s": B / ms * 1e3, "algorithmic_bytes_per_frustum": bytes_per_frustum,
+                     "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +148,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="frustums per chunk (0 = plan default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-pointset", action="store_true", help="skip the point-set operator bandwidth table")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,6 +232,8 @@ def main():
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,
                                "share_of_step_time": secs / dt}
             out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3} for k, v in agg.items()}
+        if world == 1 and not args.no_pointset:
+            out["pointset_ops"] = pointset_ops(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
