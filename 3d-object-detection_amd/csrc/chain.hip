@@ -1,25 +1,33 @@
-// Layer-chain kernels of the v1 instance-segmentation net: a workgroup carries a
-// tile of points through SEVERAL consecutive shared-MLP layers with the
-// activations resident in LDS, so that only the tile's input and its final
-// output touch HBM.
+// Layer-chain kernels of the v1 networks: a workgroup carries a tile of points
+// through SEVERAL consecutive shared-MLP layers with the activations resident in
+// LDS, so that only the tile's input and its final output touch HBM.
 //
-//   seg head : conv1 -> conv2 -> conv3 (point_feat, also stored) -> conv4 ->
-//              conv5 + max over points                128 points per workgroup
-//   seg tail : conv6 (point part + per-frustum bias) -> conv7 -> conv8 -> conv9
-//              -> conv10                               64 points per workgroup
+//   seg head  : conv1 -> conv2 -> conv3 (point_feat, also stored) -> conv4 ->
+//               conv5 + max over points                 128 points per workgroup
+//   seg tail  : conv6 (point part + per-frustum bias) -> conv7 -> conv8 -> conv9
+//               -> conv10                                64 points per workgroup
+//   obj chain : T-Net / box-net convolution stacks + max  64 object points per workgroup
 //
-// Matrix work runs on v_mfma_f32_32x32x2_f32 (exact fp32).  Per 32x32 output tile
-// a wave reads its A operand (activations) from the LDS image of the previous
-// layer - row-major with an odd row stride (K+1 words), so the 32 rows a
-// half-wave reads fall on 32 banks - and its B operand (weights) straight from
-// global memory into registers: each wave owns distinct output columns, so a
-// weight element is needed by one wave only (two in the layers where two waves
-// share a column tile) and staging it through LDS would buy nothing.  Weight
-// loads are issued one 32-deep K block ahead of the MFMAs that consume them.
-// With 8 waves per workgroup (2 per SIMD) one wave's LDS/global latency is
-// covered by the other's MFMAs.
+// Matrix work runs on v_mfma_f32_32x32x2_f32 (exact fp32).  One MFMA multiplies, for
+// every lane, A[row = lane&31][k(lane>>5)] by B[k(lane>>5)][col = lane&31]: the two
+// lane halves supply two different k.  The kernels walk K in blocks of 32 and give
+// step s (0..15) of a block the pair k = {s, 16+s}: lane half h then needs, for the
+// 16 steps, the 16 CONSECUTIVE k values 16h..16h+15 of both operands, which is what
+// makes wide loads possible:
+//   A (activations): LDS image, row-major, row stride K+4 words (16-byte aligned rows;
+//                    the 16 lanes of a ds_read_b128 group fall on 16 different
+//                    4-bank slots), read as 4 x ds_read_b128 per 32-k block;
+//   B (weights)    : global memory in a TILED layout prepared once by
+//                    fpn_tile_weights_f32 - for each (32-column tile, 32-k block) a
+//                    4 KiB chunk ordered [q][lane][4 floats], so that each of the 4
+//                    global_load_dwordx4 of a block is one fully coalesced 1 KiB read.
+//                    Each wave owns distinct output columns, so weights go straight
+//                    to registers (no LDS staging) and are requested one block ahead.
+// (Measured on MI355X: with per-k dword weight loads the same loop was limited by
+// the global-load path at ~87 % of the MFMA rate; the LDS path alone reaches 98 %.)
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "fpn_common.h"
 
@@ -28,8 +36,34 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kChainThreads = 512;
-constexpr int kKB = 16;  // MFMA k-steps (2 k each) per weight prefetch block
+// Optional in-kernel time stamps (diagnostic builds only, -DFPN_CHAIN_STAMPS): lane 0
+// of every wave records s_memtime before and after each barrier into a buffer of its
+// own; tools/chain_stamps.hip reads it back.  Compiled out of the library.
+#ifdef FPN_CHAIN_STAMPS
+__device__ unsigned long long g_stamps[1 << 22];
+__device__ __forceinline__ void fpn_stamp(int &i)
+{
+    if ((threadIdx.x & 63) == 0)
+        g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + i] = __builtin_amdgcn_s_memtime();
+    ++i;
+}
+#define FPN_SYNC()            \
+    do {                      \
+        fpn_stamp(stamp_i);   \
+        __syncthreads();      \
+        fpn_stamp(stamp_i);   \
+    } while (0)
+#define FPN_KERNEL_BEGIN \
+    int stamp_i = 0;     \
+    fpn_stamp(stamp_i);
+#define FPN_KERNEL_END fpn_stamp(stamp_i);
+#else
+#define FPN_SYNC() __syncthreads()
+#define FPN_KERNEL_BEGIN
+#define FPN_KERNEL_END
+#endif
+
+constexpr int kChainThreads = 512;  // 8 waves, 2 per SIMD
 
 // row (0..31) of accumulator register r in a 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -45,51 +79,69 @@ __device__ __forceinline__ void zero_acc(floatx16 (&acc)[TM][TN])
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 }
 
-// acc[tm][tn] += X[tm-th 32-row tile][0:2*KSTEPS] . W[0:2*KSTEPS][tn-th 32-col tile]
-//   xs : LDS, already offset to &X[first row + (lane&31)][lane>>5]; row stride XS
-//   wg : global, already offset to &W[lane>>5][first col + (lane&31)]; row stride LDW
-template <int TM, int TN, int XS>
-__device__ __forceinline__ void mfma_block(floatx16 (&acc)[TM][TN], const float *xs, const float (&bq)[TN][kKB])
+// One 32-k block of weights for one 32-column tile: 4 coalesced 16-byte loads per lane.
+// wt points at the tile's chunk for k-block 0; chunks of consecutive k-blocks follow
+// each other (256 float4 each).
+struct WBlock {
+    float4 q[4];
+};
+
+__device__ __forceinline__ void load_wblock(WBlock &b, const float4 *__restrict__ wt, int kb, int lane)
 {
 #pragma unroll
-    for (int s = 0; s < kKB; ++s) {
-        float av[TM];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) av[a] = xs[a * 32 * XS + 2 * s];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bq[b][s], acc[a][b], 0, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) b.q[i] = wt[kb * 256 + i * 64 + lane];
 }
 
-template <int TN, int LDW>
-__device__ __forceinline__ void load_wblock(float (&bq)[TN][kKB], const float *__restrict__ wg)
+__device__ __forceinline__ float wb_get(const WBlock &b, int s)
 {
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int s = 0; s < kKB; ++s) bq[b][s] = wg[(long)(2 * s) * LDW + b * 32];
+    const float4 &v = b.q[s >> 2];
+    return (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
 }
 
-template <int TM, int TN, int KSTEPS, int XS, int LDW>
-__device__ __forceinline__ void wave_gemm(floatx16 (&acc)[TM][TN], const float *xs,
-                                          const float *__restrict__ wg)
+// 16 MFMA steps of one 32-k block.  xs points at &X[first row + (lane&31)][16*(lane>>5)]
+// of k-block 0 (LDS, row stride XS words, XS % 4 == 0).
+template <int TM, int XS>
+__device__ __forceinline__ void mfma_block(floatx16 (&acc)[TM][1], const float *xs, int kb, const WBlock &b)
 {
-    static_assert(KSTEPS % (2 * kKB) == 0, "K must be a multiple of 64");
-    constexpr int NB = KSTEPS / kKB;
-    // two weight register sets, filled alternately one block ahead of their use;
-    // the pair loop is not unrolled so that only one block of loads is in flight
-    float b0[TN][kKB], b1[TN][kKB];
-    load_wblock<TN, LDW>(b0, wg);
+    float4 av[TM][4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            av[a][i] = *reinterpret_cast<const float4 *>(xs + a * 32 * XS + kb * 32 + 4 * i);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const float4 &v = av[a][s >> 2];
+            const float x = (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, wb_get(b, s), acc[a][0], 0, 0, 0);
+        }
+}
+
+// acc[tm][0] += X[tm-th 32-row tile][0:32*NKB] . W[0:32*NKB][one 32-column tile]
+// b0 must already hold k-block 0 of the tile (load_wblock(b0, wt, 0, lane)): the
+// caller requests it EARLY - before the epilogue and barrier that precede this
+// product - so that its latency is covered by work.  b0 is consumed.
+template <int TM, int NKB, int XS>
+__device__ __forceinline__ void wave_gemm(floatx16 (&acc)[TM][1], const float *xs, const float4 *__restrict__ wt,
+                                          int lane, WBlock &b0)
+{
+    static_assert(NKB % 2 == 0, "K must be a multiple of 64");
+    WBlock b1;
 #pragma unroll 1
-    for (int kb = 0; kb < NB; kb += 2) {
-        load_wblock<TN, LDW>(b1, wg + (long)(2 * (kb + 1) * kKB) * LDW);
-        mfma_block<TM, TN, XS>(acc, xs + 2 * kb * kKB, b0);
-        if (kb + 2 < NB) load_wblock<TN, LDW>(b0, wg + (long)(2 * (kb + 2) * kKB) * LDW);
-        mfma_block<TM, TN, XS>(acc, xs + 2 * (kb + 1) * kKB, b1);
+    for (int kb = 0; kb < NKB; kb += 2) {
+        load_wblock(b1, wt, kb + 1, lane);
+        mfma_block<TM, XS>(acc, xs, kb, b0);
+        if (kb + 2 < NKB) load_wblock(b0, wt, kb + 2, lane);
+        mfma_block<TM, XS>(acc, xs, kb + 1, b1);
     }
+}
+
+// start of the tiled weights of column tile ct of a layer with NKB k-blocks
+__device__ __forceinline__ const float4 *wtile(const float *wt, int ct, int nkb)
+{
+    return reinterpret_cast<const float4 *>(wt) + (size_t)ct * nkb * 256;
 }
 
 // relu(acc*scale+shift) of one 32x32 tile into an LDS activation image
@@ -109,11 +161,11 @@ struct SegHeadParams {
     int n;    // points per frustum (multiple of 128)
     int cpc;  // channels of the point cloud (3 or 4 ... <= 8)
     const float *pc;
-    const float *w1, *sc1, *sh1;  // (cpc,64)
-    const float *w2, *sc2, *sh2;  // (64,64)
-    const float *w3, *sc3, *sh3;  // (64,64)
-    const float *w4, *sc4, *sh4;  // (64,128)
-    const float *w5, *sc5, *sh5;  // (128,1024)
+    const float *w1, *sc1, *sh1;  // (cpc,64) plain
+    const float *w2, *sc2, *sh2;  // (64,64)    tiled
+    const float *w3, *sc3, *sh3;  // (64,64)    tiled
+    const float *w4, *sc4, *sh4;  // (64,128)   tiled
+    const float *w5, *sc5, *sh5;  // (128,1024) tiled
     float *point_feat;            // (rows,64)
     float *partial;               // (rows/128,1024) per-workgroup column maxima
 };
@@ -122,14 +174,19 @@ constexpr int kHeadRows = 128;
 
 __global__ __launch_bounds__(kChainThreads) void seg_head_kernel(const SegHeadParams p)
 {
-    __shared__ float B0[kHeadRows * 65];
-    __shared__ float B1[kHeadRows * 65];
-    __shared__ float B2[kHeadRows * 129];
+    __shared__ __attribute__((aligned(16))) float B0[kHeadRows * 68];
+    __shared__ __attribute__((aligned(16))) float B1[kHeadRows * 68];
+    __shared__ __attribute__((aligned(16))) float B2[kHeadRows * 132];
     __shared__ float W1s[8 * 64 + 128];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    FPN_KERNEL_BEGIN
     const int l31 = lane & 31, half = lane >> 5;
     const long row0 = (long)blockIdx.x * kHeadRows;
+
+    // first weight block of each matrix product, requested one phase early
+    WBlock wq;
+    load_wblock(wq, wtile(p.w2, w >> 2, 2), 0, lane);
 
     // conv1 on the vector ALU (K = 3 or 4): stage W1 / scale / shift in LDS
     for (int i = tid; i < p.cpc * 64; i += kChainThreads) W1s[i] = p.w1[i];
@@ -137,7 +194,7 @@ __global__ __launch_bounds__(kChainThreads) void seg_head_kernel(const SegHeadPa
         W1s[8 * 64 + tid] = p.sc1[tid];
         W1s[8 * 64 + 64 + tid] = p.sh1[tid];
     }
-    __syncthreads();
+    FPN_SYNC();
     {
         const int row = tid >> 2, cg = tid & 3;
         float x[8];
@@ -150,59 +207,64 @@ __global__ __launch_bounds__(kChainThreads) void seg_head_kernel(const SegHeadPa
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 if (c < p.cpc) v = fmaf(x[c], W1s[c * 64 + col], v);
-            B0[row * 65 + col] = fmaxf(v * W1s[8 * 64 + col] + W1s[8 * 64 + 64 + col], 0.f);
+            B0[row * 68 + col] = fmaxf(v * W1s[8 * 64 + col] + W1s[8 * 64 + 64 + col], 0.f);
         }
     }
-    __syncthreads();
+    FPN_SYNC();
 
     // conv2: B0 -> B1   (4 row tiles x 2 column tiles, one per wave)
     {
         const int rt = w & 3, ct = w >> 2;
+        const int col = ct * 32 + l31;
+        const float sc = p.sc2[col], sh = p.sh2[col];
         floatx16 acc[1][1];
         zero_acc(acc);
-        wave_gemm<1, 1, 32, 65, 64>(acc, B0 + (rt * 32 + l31) * 65 + half, p.w2 + half * 64 + ct * 32 + l31);
-        const int col = ct * 32 + l31;
-        store_tile_lds<65>(acc[0][0], B1 + rt * 32 * 65 + ct * 32, p.sc2[col], p.sh2[col], l31, half);
+        wave_gemm<1, 2, 68>(acc, B0 + (rt * 32 + l31) * 68 + 16 * half, wtile(p.w2, ct, 2), lane, wq);
+        load_wblock(wq, wtile(p.w3, ct, 2), 0, lane);
+        store_tile_lds<68>(acc[0][0], B1 + rt * 32 * 68 + ct * 32, sc, sh, l31, half);
     }
-    __syncthreads();
+    FPN_SYNC();
     // conv3: B1 -> B0 (= point_feat, also written to memory for the tail kernel)
     {
         const int rt = w & 3, ct = w >> 2;
-        floatx16 acc[1][1];
-        zero_acc(acc);
-        wave_gemm<1, 1, 32, 65, 64>(acc, B1 + (rt * 32 + l31) * 65 + half, p.w3 + half * 64 + ct * 32 + l31);
         const int col = ct * 32 + l31;
         const float sc = p.sc3[col], sh = p.sh3[col];
+        floatx16 acc[1][1];
+        zero_acc(acc);
+        wave_gemm<1, 2, 68>(acc, B1 + (rt * 32 + l31) * 68 + 16 * half, wtile(p.w3, ct, 2), lane, wq);
+        load_wblock(wq, wtile(p.w4, w & 3, 2), 0, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rt * 32 + acc_row(r, half);
             const float v = fmaxf(acc[0][0][r] * sc + sh, 0.f);
-            B0[row * 65 + col] = v;
+            B0[row * 68 + col] = v;
             p.point_feat[(row0 + row) * 64 + col] = v;
         }
     }
-    __syncthreads();
+    FPN_SYNC();
     // conv4: B0 -> B2   (4 row tiles x 4 column tiles, two row tiles per wave)
     {
         const int ct = w & 3, rt0 = (w >> 2) * 2;
-        floatx16 acc[2][1];
-        zero_acc(acc);
-        wave_gemm<2, 1, 32, 65, 128>(acc, B0 + (rt0 * 32 + l31) * 65 + half, p.w4 + half * 128 + ct * 32 + l31);
         const int col = ct * 32 + l31;
         const float sc = p.sc4[col], sh = p.sh4[col];
+        floatx16 acc[2][1];
+        zero_acc(acc);
+        wave_gemm<2, 2, 68>(acc, B0 + (rt0 * 32 + l31) * 68 + 16 * half, wtile(p.w4, ct, 2), lane, wq);
+        load_wblock(wq, wtile(p.w5, w, 4), 0, lane);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) store_tile_lds<129>(acc[a][0], B2 + (rt0 + a) * 32 * 129 + ct * 32, sc, sh, l31, half);
+        for (int a = 0; a < 2; ++a) store_tile_lds<132>(acc[a][0], B2 + (rt0 + a) * 32 * 132 + ct * 32, sc, sh, l31, half);
     }
-    __syncthreads();
+    FPN_SYNC();
     // conv5 + max over the 128 points: wave w owns column tiles w, w+8, w+16, w+24
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
         const int ct = w + 8 * i;
-        floatx16 acc[4][1];
-        zero_acc(acc);
-        wave_gemm<4, 1, 64, 129, 1024>(acc, B2 + l31 * 129 + half, p.w5 + half * 1024 + ct * 32 + l31);
         const int col = ct * 32 + l31;
         const float sc = p.sc5[col], sh = p.sh5[col];
+        floatx16 acc[4][1];
+        zero_acc(acc);
+        wave_gemm<4, 4, 132>(acc, B2 + l31 * 132 + 16 * half, wtile(p.w5, ct, 4), lane, wq);
+        if (i < 3) load_wblock(wq, wtile(p.w5, ct + 8, 4), 0, lane);
         float m = 0.f;  // ReLU output is >= 0
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -211,6 +273,7 @@ __global__ __launch_bounds__(kChainThreads) void seg_head_kernel(const SegHeadPa
         m = fmaxf(m, __shfl_xor(m, 32));
         if (half == 0) p.partial[(long)blockIdx.x * 1024 + col] = m;
     }
+    FPN_KERNEL_END
 }
 
 // ---------------------------------------------------------------------------
@@ -221,11 +284,11 @@ struct SegTailParams {
     int n;  // points per frustum (multiple of 64)
     const float *point_feat;  // (rows,64)
     const float *gbias;       // (rows/n,512): [global_feat | one_hot] . W6[64:]
-    const float *w6, *sc6, *sh6;  // (64,512) point rows of conv6
-    const float *w7, *sc7, *sh7;  // (512,256)
-    const float *w8, *sc8, *sh8;  // (256,128)
-    const float *w9, *sc9, *sh9;  // (128,128)
-    const float *w10, *b10;       // (128,2), (2)
+    const float *w6, *sc6, *sh6;  // (64,512)  point rows of conv6, tiled
+    const float *w7, *sc7, *sh7;  // (512,256) tiled
+    const float *w8, *sc8, *sh8;  // (256,128) tiled
+    const float *w9, *sc9, *sh9;  // (128,128) tiled
+    const float *w10, *b10;       // (128,2) plain, (2)
     float *logits;                // (rows,2)
 };
 
@@ -233,73 +296,86 @@ constexpr int kTailRows = 64;
 
 __global__ __launch_bounds__(kChainThreads) void seg_tail_kernel(const SegTailParams p)
 {
-    __shared__ float PF[kTailRows * 65];
-    __shared__ float H[kTailRows * 129];   // conv6 chunk (128 wide); later conv8's output
-    __shared__ float A7[kTailRows * 257];  // conv7's output; later conv9's output (stride 129)
+    __shared__ __attribute__((aligned(16))) float PF[kTailRows * 68];
+    __shared__ __attribute__((aligned(16))) float H[kTailRows * 132];   // conv6 chunk (128 wide); later conv8's output
+    __shared__ __attribute__((aligned(16))) float A7[kTailRows * 260];  // conv7's output; later conv9's output (stride 132)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    FPN_KERNEL_BEGIN
     const int l31 = lane & 31, half = lane >> 5;
     const long row0 = (long)blockIdx.x * kTailRows;
     const long frustum = row0 / p.n;
+
+    const int rt = w & 1, ct = w >> 1;  // tile of a 64 x 128 output (conv6 chunk, conv8, conv9)
+    // first weight block of every product is requested one phase early (wq = the
+    // block for the next 1-tile product, wq7 = for the next conv7 partial product)
+    WBlock wq, wq7;
+    load_wblock(wq, wtile(p.w6, ct, 2), 0, lane);
 
     // point_feat tile -> LDS
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int e = tid + kChainThreads * i;
         const int row = e >> 4, q = e & 15;
-        const float4 v = *reinterpret_cast<const float4 *>(p.point_feat + (row0 + row) * 64 + 4 * q);
-        float *d = PF + row * 65 + 4 * q;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        *reinterpret_cast<float4 *>(PF + row * 68 + 4 * q) =
+            *reinterpret_cast<const float4 *>(p.point_feat + (row0 + row) * 64 + 4 * q);
     }
-    __syncthreads();
+    FPN_SYNC();
 
     floatx16 acc7[2][1];
     zero_acc(acc7);
-    const int rt = w & 1, ct = w >> 1;  // tile of a 64 x 128 output (conv6 chunk, conv8, conv9)
+    const float4 *w7t = wtile(p.w7, w, 16);  // conv7: wave w owns output columns [32 w, 32 w + 32)
 #pragma unroll 1
     for (int kc = 0; kc < 4; ++kc) {
         // conv6, output columns [128 kc, 128 kc + 128): PF -> H
         {
+            const int col = kc * 128 + ct * 32 + l31;
+            // epilogue constants are requested before the product, not after it
+            const float g = p.gbias[frustum * 512 + col], sc = p.sc6[col], sh = p.sh6[col];
             floatx16 acc[1][1];
             zero_acc(acc);
-            const int col = kc * 128 + ct * 32 + l31;
-            wave_gemm<1, 1, 32, 65, 512>(acc, PF + (rt * 32 + l31) * 65 + half, p.w6 + half * 512 + col);
-            const float g = p.gbias[frustum * 512 + col], sc = p.sc6[col], sh = p.sh6[col];
+            wave_gemm<1, 2, 68>(acc, PF + (rt * 32 + l31) * 68 + 16 * half, wtile(p.w6, kc * 4 + ct, 2), lane, wq);
+            load_wblock(wq7, w7t, kc * 4, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                H[(rt * 32 + acc_row(r, half)) * 129 + ct * 32 + l31] = fmaxf((acc[0][0][r] + g) * sc + sh, 0.f);
+                H[(rt * 32 + acc_row(r, half)) * 132 + ct * 32 + l31] = fmaxf((acc[0][0][r] + g) * sc + sh, 0.f);
         }
-        __syncthreads();
-        // conv7 += H . W7[128 kc : 128 kc + 128, :]; wave w owns output columns [32 w, 32 w + 32)
-        wave_gemm<2, 1, 64, 129, 256>(acc7, H + l31 * 129 + half, p.w7 + (long)(kc * 128 + half) * 256 + w * 32 + l31);
-        __syncthreads();
+        FPN_SYNC();
+        // conv7 += H . W7[128 kc : 128 kc + 128, :]  (k-blocks 4 kc .. 4 kc + 3 of the tile)
+        wave_gemm<2, 4, 132>(acc7, H + l31 * 132 + 16 * half, w7t + (size_t)kc * 4 * 256, lane, wq7);
+        if (kc < 3) load_wblock(wq, wtile(p.w6, (kc + 1) * 4 + ct, 2), 0, lane);
+        else load_wblock(wq, wtile(p.w8, ct, 8), 0, lane);
+        FPN_SYNC();
     }
     {
         const int col = w * 32 + l31;
         const float sc = p.sc7[col], sh = p.sh7[col];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) store_tile_lds<257>(acc7[a][0], A7 + a * 32 * 257 + w * 32, sc, sh, l31, half);
+        for (int a = 0; a < 2; ++a) store_tile_lds<260>(acc7[a][0], A7 + a * 32 * 260 + w * 32, sc, sh, l31, half);
     }
-    __syncthreads();
-    // conv8: A7 -> H (stride 129)
+    FPN_SYNC();
+    // conv8: A7 -> H (stride 132)
     {
+        const int col = ct * 32 + l31;
+        const float sc = p.sc8[col], sh = p.sh8[col];
         floatx16 acc[1][1];
         zero_acc(acc);
-        const int col = ct * 32 + l31;
-        wave_gemm<1, 1, 128, 257, 128>(acc, A7 + (rt * 32 + l31) * 257 + half, p.w8 + half * 128 + col);
-        store_tile_lds<129>(acc[0][0], H + rt * 32 * 129 + ct * 32, p.sc8[col], p.sh8[col], l31, half);
+        wave_gemm<1, 8, 260>(acc, A7 + (rt * 32 + l31) * 260 + 16 * half, wtile(p.w8, ct, 8), lane, wq);
+        load_wblock(wq, wtile(p.w9, ct, 4), 0, lane);
+        store_tile_lds<132>(acc[0][0], H + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
     }
-    __syncthreads();
-    // conv9: H -> A7 region (stride 129)
+    FPN_SYNC();
+    // conv9: H -> A7 region (stride 132)
     float *A9 = A7;
     {
+        const int col = ct * 32 + l31;
+        const float sc = p.sc9[col], sh = p.sh9[col];
         floatx16 acc[1][1];
         zero_acc(acc);
-        const int col = ct * 32 + l31;
-        wave_gemm<1, 1, 64, 129, 128>(acc, H + (rt * 32 + l31) * 129 + half, p.w9 + half * 128 + col);
-        store_tile_lds<129>(acc[0][0], A9 + rt * 32 * 129 + ct * 32, p.sc9[col], p.sh9[col], l31, half);
+        wave_gemm<1, 4, 132>(acc, H + (rt * 32 + l31) * 132 + 16 * half, wtile(p.w9, ct, 4), lane, wq);
+        store_tile_lds<132>(acc[0][0], A9 + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
     }
-    __syncthreads();
+    FPN_SYNC();
     // conv10 (128 -> 2, no batch norm, no activation) on the vector ALU: 8 lanes per point
     {
         const int row = tid >> 3, part = tid & 7;
@@ -307,7 +383,7 @@ __global__ __launch_bounds__(kChainThreads) void seg_tail_kernel(const SegTailPa
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int k = part * 16 + j;
-            const float a = A9[row * 129 + k];
+            const float a = A9[row * 132 + k];
             s0 = fmaf(a, p.w10[k * 2 + 0], s0);
             s1 = fmaf(a, p.w10[k * 2 + 1], s1);
         }
@@ -316,11 +392,10 @@ __global__ __launch_bounds__(kChainThreads) void seg_tail_kernel(const SegTailPa
             s0 += __shfl_xor(s0, off);
             s1 += __shfl_xor(s1, off);
         }
-        if (part == 0) {
-            float2 o = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
-            *reinterpret_cast<float2 *>(p.logits + (row0 + row) * 2) = o;
-        }
+        if (part == 0)
+            *reinterpret_cast<float2 *>(p.logits + (row0 + row) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
     }
+    FPN_KERNEL_END
 }
 
 // ---------------------------------------------------------------------------
@@ -335,10 +410,10 @@ struct ObjChainParams {
     int m;                // object points per frustum (multiple of 64)
     const float *obj;     // (rows,3)
     const float *delta;   // (rows/m,3) subtracted from every point of the frustum, or NULL
-    const float *w1, *sc1, *sh1;  // (3,128)
-    const float *w2, *sc2, *sh2;  // (128,128)
-    const float *w3, *sc3, *sh3;  // (128,256)
-    const float *w4, *sc4, *sh4;  // (256,512)  box net only
+    const float *w1, *sc1, *sh1;  // (3,128) plain
+    const float *w2, *sc2, *sh2;  // (128,128) tiled
+    const float *w3, *sc3, *sh3;  // (128,256) tiled
+    const float *w4, *sc4, *sh4;  // (256,512) tiled, box net only
     float *partial;               // (rows/64, 256 or 512) per-workgroup column maxima
 };
 
@@ -347,21 +422,25 @@ constexpr int kObjRows = 64;
 template <bool BOX>
 __global__ __launch_bounds__(kChainThreads) void obj_chain_kernel(const ObjChainParams p)
 {
-    __shared__ float A[kObjRows * 129];
-    __shared__ float B[kObjRows * 129];
-    __shared__ float C[BOX ? kObjRows * 257 : 1];
+    __shared__ __attribute__((aligned(16))) float A[kObjRows * 132];
+    __shared__ __attribute__((aligned(16))) float B[kObjRows * 132];
+    __shared__ __attribute__((aligned(16))) float C[BOX ? kObjRows * 260 : 4];
     __shared__ float W1s[3 * 128 + 256];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    FPN_KERNEL_BEGIN
     const int l31 = lane & 31, half = lane >> 5;
     const long row0 = (long)blockIdx.x * kObjRows;
+
+    WBlock wq;  // first weight block of the next product, requested one phase early
+    load_wblock(wq, wtile(p.w2, w >> 1, 4), 0, lane);
 
     if (tid < 3 * 128) W1s[tid] = p.w1[tid];
     if (tid < 128) {
         W1s[3 * 128 + tid] = p.sc1[tid];
         W1s[3 * 128 + 128 + tid] = p.sh1[tid];
     }
-    __syncthreads();
+    FPN_SYNC();
     {   // layer 1 (K = 3) on the vector ALU: 8 lanes per point, 16 columns each
         const int row = tid >> 3, cg = tid & 7;
         const float *src = p.obj + (row0 + row) * 3;
@@ -374,25 +453,28 @@ __global__ __launch_bounds__(kChainThreads) void obj_chain_kernel(const ObjChain
         for (int j = 0; j < 16; ++j) {
             const int col = cg * 16 + j;
             float v = fmaf(x2, W1s[256 + col], fmaf(x1, W1s[128 + col], x0 * W1s[col]));
-            A[row * 129 + col] = fmaxf(v * W1s[3 * 128 + col] + W1s[3 * 128 + 128 + col], 0.f);
+            A[row * 132 + col] = fmaxf(v * W1s[3 * 128 + col] + W1s[3 * 128 + 128 + col], 0.f);
         }
     }
-    __syncthreads();
+    FPN_SYNC();
     {   // layer 2: A -> B, 2 row tiles x 4 column tiles
         const int rt = w & 1, ct = w >> 1;
+        const int col = ct * 32 + l31;
+        const float sc = p.sc2[col], sh = p.sh2[col];
         floatx16 acc[1][1];
         zero_acc(acc);
-        const int col = ct * 32 + l31;
-        wave_gemm<1, 1, 64, 129, 128>(acc, A + (rt * 32 + l31) * 129 + half, p.w2 + half * 128 + col);
-        store_tile_lds<129>(acc[0][0], B + rt * 32 * 129 + ct * 32, p.sc2[col], p.sh2[col], l31, half);
+        wave_gemm<1, 4, 132>(acc, A + (rt * 32 + l31) * 132 + 16 * half, wtile(p.w2, ct, 4), lane, wq);
+        load_wblock(wq, wtile(p.w3, w, 4), 0, lane);
+        store_tile_lds<132>(acc[0][0], B + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
     }
-    __syncthreads();
+    FPN_SYNC();
     {   // layer 3: B -> 256 columns, wave w owns column tile w and both row tiles
+        const int col = w * 32 + l31;
+        const float sc = p.sc3[col], sh = p.sh3[col];
         floatx16 acc[2][1];
         zero_acc(acc);
-        const int col = w * 32 + l31;
-        wave_gemm<2, 1, 64, 129, 256>(acc, B + l31 * 129 + half, p.w3 + half * 256 + col);
-        const float sc = p.sc3[col], sh = p.sh3[col];
+        wave_gemm<2, 4, 132>(acc, B + l31 * 132 + 16 * half, wtile(p.w3, w, 4), lane, wq);
+        if (BOX) load_wblock(wq, wtile(p.w4, w, 8), 0, lane);
         if (!BOX) {
             float m = 0.f;
 #pragma unroll
@@ -404,18 +486,20 @@ __global__ __launch_bounds__(kChainThreads) void obj_chain_kernel(const ObjChain
             return;
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) store_tile_lds<257>(acc[a][0], C + a * 32 * 257 + w * 32, sc, sh, l31, half);
+        for (int a = 0; a < 2; ++a) store_tile_lds<260>(acc[a][0], C + a * 32 * 260 + w * 32, sc, sh, l31, half);
     }
     if (BOX) {
-        __syncthreads();
+        FPN_SYNC();
         // layer 4: C -> 512 columns + max over the 64 points; column tiles w and w + 8
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
+            const int ct = w + 8 * i;
+            const int col = ct * 32 + l31;
+            const float sc = p.sc4[col], sh = p.sh4[col];
             floatx16 acc[2][1];
             zero_acc(acc);
-            const int col = (w + 8 * i) * 32 + l31;
-            wave_gemm<2, 1, 128, 257, 512>(acc, C + l31 * 257 + half, p.w4 + half * 512 + col);
-            const float sc = p.sc4[col], sh = p.sh4[col];
+            wave_gemm<2, 8, 260>(acc, C + l31 * 260 + 16 * half, wtile(p.w4, ct, 8), lane, wq);
+            if (i == 0) load_wblock(wq, wtile(p.w4, ct + 8, 8), 0, lane);
             float m = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -427,12 +511,39 @@ __global__ __launch_bounds__(kChainThreads) void obj_chain_kernel(const ObjChain
     }
 }
 
+// w (cin,cout) row-major -> tiled: for column tile ct, k-block kb, load index q,
+// lane l, element j:  wt[(((ct*NKB + kb)*4 + q)*64 + l)*4 + j] =
+//                     w[kb*32 + 16*(l>>5) + 4*q + j][ct*32 + (l&31)]
+__global__ void tile_weights_kernel(int cin, int cout, const float *__restrict__ w, float *__restrict__ wt)
+{
+    const long total = (long)cin * cout;
+    const int nkb = cin / 32;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = e & 3, l = (e >> 2) & 63, q = (e >> 8) & 3;
+        const long blk = e >> 10;
+        const int kb = (int)(blk % nkb), ct = (int)(blk / nkb);
+        const int k = kb * 32 + 16 * (l >> 5) + 4 * q + j, col = ct * 32 + (l & 31);
+        wt[e] = w[(long)k * cout + col];
+    }
+}
+
 }  // namespace
 }  // namespace fpn
 
 using namespace fpn;
 
 extern "C" {
+
+int fpn_tile_weights_f32(int cin, int cout, const float *w, float *w_tiled, void *stream)
+{
+    FPN_REQUIRE(cin >= 64 && cin % 64 == 0 && cout >= 32 && cout % 32 == 0,
+                "tile_weights: cin (%d) must be a multiple of 64 and cout (%d) a multiple of 32", cin, cout);
+    FPN_REQUIRE(w && w_tiled && w != w_tiled, "tile_weights: null or aliased pointer");
+    const long total = (long)cin * cout;
+    hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       as_stream(stream), cin, cout, w, w_tiled);
+    return check_launch("fpn_tile_weights_f32");
+}
 
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,
                         float *point_feat, float *partial_max, void *stream)
@@ -474,10 +585,11 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
     return check_launch("fpn_v1_seg_tail_f32");
 }
 
-}  // extern "C"
+// rows of partial_max per workgroup: which = 0 seg head, 1 object chains
+int fpn_v1_chain_rows(int which) { return which == 0 ? kHeadRows : kObjRows; }
 
-extern "C" int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
-                                    const float *const *layers, float *partial_max, void *stream)
+int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
+                         const float *const *layers, float *partial_max, void *stream)
 {
     FPN_REQUIRE(rows >= 0 && m >= 1, "v1_obj_chain: bad size");
     FPN_REQUIRE(m % kObjRows == 0 && rows % m == 0, "v1_obj_chain: object points per frustum (%d) must be a multiple of %d", m, kObjRows);
@@ -497,3 +609,5 @@ extern "C" int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj,
     else hipLaunchKernelGGL(obj_chain_kernel<false>, grid, dim3(kChainThreads), 0, as_stream(stream), p);
     return check_launch("fpn_v1_obj_chain_f32");
 }
+
+}  // extern "C"

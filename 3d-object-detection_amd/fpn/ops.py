@@ -1,4 +1,6 @@
 """Thin tensor-level callers of the shared-MLP and masking entry points."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -102,6 +104,23 @@ def pointer_table(tensors):
     for i, t in enumerate(tensors):
         arr[i] = t.data_ptr()
     return arr
+
+
+def chain_rows(which):
+    """Rows per workgroup of the chain kernels (0: seg head, 1: object chains): the
+    granularity of their partial_max outputs."""
+    return _lib.load().fpn_v1_chain_rows(which)
+
+
+def tile_weights(w):
+    """w (cin,cout) row-major -> the chain kernels' tiled layout (a flat tensor of
+    cin*cout floats) through fpn_tile_weights_f32."""
+    _lib.require_device_tensor("w", w, torch.float32, 2)
+    cin, cout = w.shape
+    out = torch.empty(cin * cout, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().fpn_tile_weights_f32(cin, cout, _lib.ptr(w), _lib.ptr(out), _lib.stream_of(w)))
+    return out
 
 
 def v1_seg_head(pc2d, n, table, point_feat, partial_max):

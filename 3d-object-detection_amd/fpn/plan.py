@@ -96,16 +96,24 @@ class V1Plan:
         self.w6_glob = w6[64:].contiguous()     # rows of [global_feat | one_hot]
         # pointer tables of the chain kernels ({w, scale, shift} per layer; a layer
         # without batch norm gets an explicit scale of ones)
-        def triple(scope, w=None):
+        if not self.chain:
+            self._version = st.version
+            return
+
+        def triple(scope, w=None, tiled=True):
             wt, scale, shift, _ = self.p[scope]
             if scale is None:
                 scale = torch.ones_like(shift)
-            return [wt if w is None else w, scale, shift]
-        self._head_tensors = sum([triple(s) for s in ("conv1", "conv2", "conv3", "conv4", "conv5")], [])
+            wt = wt if w is None else w
+            # matrix-core layers read their weights in the tiled layout; the first
+            # layer of each stack (K = 3 or 4) runs on the vector ALU from plain w
+            return [ops.tile_weights(wt.contiguous()) if tiled else wt, scale, shift]
+        self._head_tensors = triple("conv1", tiled=False) + \
+            sum([triple(s) for s in ("conv2", "conv3", "conv4", "conv5")], [])
         self._tail_tensors = triple("conv6", self.w6_pt) + triple("conv7") + triple("conv8") + triple("conv9") + \
             [self.p["conv10"][0], self.p["conv10"][2]]
-        self._tnet_tensors = sum([triple(s) for s, _ in TNET_CONV], [])
-        self._box_tensors = sum([triple(s) for s, _ in BOX_CONV], [])
+        self._tnet_tensors = sum([triple(s, tiled=i > 0) for i, (s, _) in enumerate(TNET_CONV)], [])
+        self._box_tensors = sum([triple(s, tiled=i > 0) for i, (s, _) in enumerate(BOX_CONV)], [])
         self._head_table = ops.pointer_table(self._head_tensors)
         self._tail_table = ops.pointer_table(self._tail_tensors)
         self._tnet_table = ops.pointer_table(self._tnet_tensors)
@@ -157,9 +165,10 @@ class V1Plan:
         gcat[:, 1024:] = one_hot                                        # concat one-hot :64
         if self.chain and n % 128 == 0:
             point_feat = torch.empty((rows, 64), dtype=torch.float32, device=dev)
-            partial = torch.empty((rows // 128, 1024), dtype=torch.float32, device=dev)
+            hrows = ops.chain_rows(0)     # points per workgroup of the head kernel
+            partial = torch.empty((rows // hrows, 1024), dtype=torch.float32, device=dev)
             ops.v1_seg_head(x, n, self._head_table, point_feat, partial)          # conv1..conv5 :41-60
-            ops.max_pool_rows(partial, n // 128, out=gcat[:, :1024])              # maxpool :61
+            ops.max_pool_rows(partial, n // hrows, out=gcat[:, :1024])            # maxpool :61
             # frustum-constant part of conv6: [global_feat | one_hot] . W6[64:]
             gbias = ops.shared_mlp(gcat, self.w6_glob, None, None, relu=False)
             logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
@@ -191,10 +200,11 @@ class V1Plan:
         tcat[:, 256:] = one_hot
         obj2d = obj.reshape(b * m, 3)
         if self.chain:
-            opart = torch.empty((b * m // 64, 512), dtype=torch.float32, device=dev)
-            tpart = opart.view(-1)[:b * m // 64 * 256].view(b * m // 64, 256)
+            orows = ops.chain_rows(1)     # object points per workgroup of the chain kernels
+            opart = torch.empty((b * m // orows, 512), dtype=torch.float32, device=dev)
+            tpart = opart.view(-1)[:b * m // orows * 256].view(b * m // orows, 256)
             ops.v1_obj_chain(obj2d, m, False, None, self._tnet_table, tpart)
-            ops.max_pool_rows(tpart, m // 64, out=tcat[:, :256])
+            ops.max_pool_rows(tpart, m // orows, out=tcat[:, :256])
         else:
             t = self._layer(obj2d, "conv-reg1-stage1")
             t = self._layer(t, "conv-reg2-stage1")
@@ -210,7 +220,7 @@ class V1Plan:
         if self.chain:
             # the kernel subtracts center_delta while loading the tile (:176-177)
             ops.v1_obj_chain(obj2d, m, True, center_delta, self._box_table, opart)
-            ops.max_pool_rows(opart, m // 64, out=bcat[:, :512])
+            ops.max_pool_rows(opart, m // orows, out=bcat[:, :512])
         else:
             obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)     # :176-177
             t = self._layer(obj_new, "conv-reg1")

@@ -208,6 +208,29 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
                                size_t workspace_bytes, void *stream);
 
 /*
+ * Weight layout of the layer-chain kernels below.  They feed the matrix cores
+ * straight from global memory, one 16-byte load per lane; this re-orders a
+ * row-major w (cin,cout) so that those loads are contiguous across a wavefront:
+ *   w_tiled[(((ct*(cin/32) + kb)*4 + q)*64 + l)*4 + j]
+ *       = w[kb*32 + 16*(l/32) + 4*q + j][ct*32 + l%32]
+ * (ct = 32-column tile, kb = 32-row block, l = lane 0..63, q,j = 0..3).  Done once
+ * per weight matrix when a checkpoint is loaded; w_tiled has cin*cout floats and
+ * must not alias w.  cin % 64 == 0, cout % 32 == 0.  No counterpart in the
+ * reference (TensorFlow owns its conv kernels' layouts, models/tf_util.py:142-170).
+ */
+int fpn_tile_weights_f32(int cin, int cout, const float *w, float *w_tiled, void *stream);
+
+/* Points per workgroup of fpn_v1_seg_head_f32 (which = 0) or fpn_v1_obj_chain_f32
+ * (which = 1): the row granularity of their partial_max outputs. */
+int fpn_v1_chain_rows(int which);
+
+/* Largest squared distance s for which the reference's ball test
+ * max(sqrtf(s), 1e-20f) < radius holds (models/tf_ops/grouping/tf_grouping_g.cu:24),
+ * or -1 when no distance passes, so that fpn_query_ball_point can compare squared distances and still accept
+ * exactly the same points. */
+float fpn_ball_threshold(float radius);
+
+/*
  * First half of the v1 instance-segmentation net as ONE kernel: conv1..conv5 of
  * get_instance_seg_v1_net (models/frustum_pointnets_v1.py:41-60) with their
  * bias/batch-norm/ReLU, plus the per-128-point part of the max-pool at :61.
@@ -215,11 +238,12 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
  * point cloud is read and only conv3's output (`point_feat`, :49, needed again by
  * conv6) and the column maxima are written.
  *   pc (rows, cpc) with 3 <= cpc <= 8;  rows = frustums * n, n % 128 == 0.
- *   layers: HOST array of 15 device pointers {w,scale,shift} x {conv1..conv5},
- *           w row-major (cin,cout), scale/shift as in fpn_shared_mlp_f32 (all non-NULL).
- *   point_feat (rows,64); partial_max (rows/128, 1024): the maximum of conv5's
- *   output over each workgroup's 128 points; finish with
- *   fpn_max_pool_rows(rows/128, 1024, n/128, partial_max, 1024, global_feat, ld).
+ *   layers: HOST array of 15 device pointers {w,scale,shift} x {conv1..conv5};
+ *           conv1's w row-major (cpc,64), the other four in the TILED layout of
+ *           fpn_tile_weights_f32; scale/shift as in fpn_shared_mlp_f32 (all non-NULL).
+ *   point_feat (rows,64); partial_max (rows/R, 1024) with R = fpn_v1_chain_rows(0)
+ *   (128): the maximum of conv5's output over each workgroup's R points; finish with
+ *   fpn_max_pool_rows(rows/R, 1024, n/R, partial_max, 1024, global_feat, ld).
  */
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,
                         float *point_feat, float *partial_max, void *stream);
@@ -236,7 +260,9 @@ int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float 
  * exist as a whole.
  *   point_feat (rows,64); group_bias (rows/n, 512); n % 64 == 0.
  *   layers: HOST array of 14 device pointers {w6[0:64],scale6,shift6, w7,scale7,
- *           shift7, w8,scale8,shift8, w9,scale9,shift9, w10, bias10} (all non-NULL).
+ *           shift7, w8,scale8,shift8, w9,scale9,shift9, w10, bias10} (all non-NULL);
+ *           w6[0:64], w7, w8, w9 in the TILED layout of fpn_tile_weights_f32, w10
+ *           row-major (128,2).
  *   logits (rows,2).
  */
 int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_bias,
@@ -255,8 +281,11 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
  * as the tile is loaded: the translation to the T-Net's centre estimate of
  * frustum_pointnets_v1.py:176-177.
  *   obj (rows,3), rows = frustums * m, m % 64 == 0.
- *   layers: HOST array of 9 (T-Net) or 12 (box) device pointers {w,scale,shift}.
- *   partial_max (rows/64, 256 or 512); finish with fpn_max_pool_rows over m/64 rows.
+ *   layers: HOST array of 9 (T-Net) or 12 (box) device pointers {w,scale,shift};
+ *           the first layer's w row-major (3,128), the others in the TILED layout
+ *           of fpn_tile_weights_f32.
+ *   partial_max (rows/R, 256 or 512) with R = fpn_v1_chain_rows(1) (64); finish
+ *   with fpn_max_pool_rows over m/R rows.
  */
 int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
                          const float *const *layers, float *partial_max, void *stream);
