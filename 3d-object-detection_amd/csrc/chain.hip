@@ -100,35 +100,136 @@ __device__ __forceinline__ float wb_get(const WBlock &b, int s)
 
 // 16 MFMA steps of one 32-k block.  xs points at &X[first row + (lane&31)][16*(lane>>5)]
 // of k-block 0 (LDS, row stride XS words, XS % 4 == 0).
+template <int TM>
+struct ABlock {
+    float4 v[TM][4];
+};
+
 template <int TM, int XS>
-__device__ __forceinline__ void mfma_block(floatx16 (&acc)[TM][1], const float *xs, int kb, const WBlock &b)
+__device__ __forceinline__ void load_ablock(ABlock<TM> &a, const float *xs, int kb)
 {
-    float4 av[TM][4];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            av[a][i] = *reinterpret_cast<const float4 *>(xs + a * 32 * XS + kb * 32 + 4 * i);
+            a.v[t][i] = *reinterpret_cast<const float4 *>(xs + t * 32 * XS + kb * 32 + 4 * i);
+}
+
+template <int TM>
+__device__ __forceinline__ void mfma_regs(floatx16 (&acc)[TM][1], const ABlock<TM> &a, const WBlock &b)
+{
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const float4 &v = av[a][s >> 2];
+        for (int t = 0; t < TM; ++t) {
+            const float4 &v = a.v[t][s >> 2];
             const float x = (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
-            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, wb_get(b, s), acc[a][0], 0, 0, 0);
+            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, wb_get(b, s), acc[t][0], 0, 0, 0);
         }
+}
+
+template <int TM, int XS>
+__device__ __forceinline__ void mfma_block(floatx16 (&acc)[TM][1], const float *xs, int kb, const WBlock &b)
+{
+    ABlock<TM> a;
+    load_ablock<TM, XS>(a, xs, kb);
+    mfma_regs<TM>(acc, a, b);
 }
 
 // acc[tm][0] += X[tm-th 32-row tile][0:32*NKB] . W[0:32*NKB][one 32-column tile]
 // b0 must already hold k-block 0 of the tile (load_wblock(b0, wt, 0, lane)): the
 // caller requests it EARLY - before the epilogue and barrier that precede this
 // product - so that its latency is covered by work.  b0 is consumed.
+//
+// FPN_CHAIN_PIPELINE 1: software pipeline at half-block granularity.  While the 8*TM
+// MFMAs of one half-block run, the activations of the NEXT half-block (2*TM
+// ds_read_b128) and, every other half, the weights of the next block (4
+// global_load_dwordx4) are requested into a second register set; the order is pinned
+// with sched_group_barrier (one load in the shadow of each MFMA), because left alone
+// the scheduler sinks the loads to just before their use.  Loads past the end are
+// clamped to the last block (harmless re-reads) so that the loop body is one basic
+// block.  FPN_CHAIN_PIPELINE 0: plain form, scheduling left to the compiler.
+#ifndef FPN_CHAIN_PIPELINE
+#define FPN_CHAIN_PIPELINE 1
+#endif
+
+template <int TM>
+struct AHalf {
+    float4 v[TM][2];
+};
+
+// half-block h covers, for lane half hl, k = 32*(h/2) + 16*hl + 8*(h%2) + [0,8)
+template <int TM, int XS>
+__device__ __forceinline__ void load_ahalf(AHalf<TM> &a, const float *xs, int h)
+{
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            a.v[t][i] = *reinterpret_cast<const float4 *>(xs + t * 32 * XS + (h >> 1) * 32 + (h & 1) * 8 + 4 * i);
+}
+
+template <int TM, int HSEL>
+__device__ __forceinline__ void mfma_half(floatx16 (&acc)[TM][1], const AHalf<TM> &a, const WBlock &b)
+{
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const float4 &v = a.v[t][s >> 2];
+            const float x = (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
+            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, wb_get(b, 8 * HSEL + s), acc[t][0], 0, 0, 0);
+        }
+}
+
+// scheduling groups of one half-block: one load in the shadow of each of the first
+// MFMAs, then the rest of the MFMAs
+template <int TM, bool VMEM>
+__device__ __forceinline__ void sched_half()
+{
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+    if (VMEM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * TM - 2 * TM - (VMEM ? 4 : 0), 0);
+}
+
 template <int TM, int NKB, int XS>
 __device__ __forceinline__ void wave_gemm(floatx16 (&acc)[TM][1], const float *xs, const float4 *__restrict__ wt,
                                           int lane, WBlock &b0)
 {
     static_assert(NKB % 2 == 0, "K must be a multiple of 64");
     WBlock b1;
+#if FPN_CHAIN_PIPELINE
+    AHalf<TM> ae, ao;
+    load_ahalf<TM, XS>(ae, xs, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; kb += 2) {
+        const int kbn = kb + 2 < NKB ? kb + 2 : kb;
+        load_ahalf<TM, XS>(ao, xs, 2 * kb + 1);
+        load_wblock(b1, wt, kb + 1, lane);
+        mfma_half<TM, 0>(acc, ae, b0);
+        load_ahalf<TM, XS>(ae, xs, 2 * kb + 2);
+        mfma_half<TM, 1>(acc, ao, b0);
+        load_ahalf<TM, XS>(ao, xs, 2 * kb + 3);
+        load_wblock(b0, wt, kbn, lane);
+        mfma_half<TM, 0>(acc, ae, b1);
+        load_ahalf<TM, XS>(ae, xs, 2 * kbn);
+        mfma_half<TM, 1>(acc, ao, b1);
+        sched_half<TM, true>();
+        sched_half<TM, false>();
+        sched_half<TM, true>();
+        sched_half<TM, false>();
+    }
+#else
 #pragma unroll 1
     for (int kb = 0; kb < NKB; kb += 2) {
         load_wblock(b1, wt, kb + 1, lane);
@@ -136,6 +237,7 @@ __device__ __forceinline__ void wave_gemm(floatx16 (&acc)[TM][1], const float *x
         if (kb + 2 < NKB) load_wblock(b0, wt, kb + 2, lane);
         mfma_block<TM, XS>(acc, xs, kb + 1, b1);
     }
+#endif
 }
 
 // start of the tiled weights of column tile ct of a layer with NKB k-blocks
@@ -177,7 +279,6 @@ __global__ __launch_bounds__(kChainThreads) void seg_head_kernel(const SegHeadPa
     __shared__ __attribute__((aligned(16))) float B0[kHeadRows * 68];
     __shared__ __attribute__((aligned(16))) float B1[kHeadRows * 68];
     __shared__ __attribute__((aligned(16))) float B2[kHeadRows * 132];
-    __shared__ float W1s[8 * 64 + 128];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     FPN_KERNEL_BEGIN
@@ -188,27 +289,26 @@ __global__ __launch_bounds__(kChainThreads) void seg_head_kernel(const SegHeadPa
     WBlock wq;
     load_wblock(wq, wtile(p.w2, w >> 2, 2), 0, lane);
 
-    // conv1 on the vector ALU (K = 3 or 4): stage W1 / scale / shift in LDS
-    for (int i = tid; i < p.cpc * 64; i += kChainThreads) W1s[i] = p.w1[i];
-    if (tid < 64) {
-        W1s[8 * 64 + tid] = p.sc1[tid];
-        W1s[8 * 64 + 64 + tid] = p.sh1[tid];
-    }
-    FPN_SYNC();
+    // conv1 (K = cpc <= 8) on the matrix cores too, operands straight from memory:
+    // step t multiplies channels {2t, 2t+1}; 4 row tiles x 2 column tiles, one per wave
     {
-        const int row = tid >> 2, cg = tid & 3;
-        float x[8];
+        const int rt = w & 3, ct = w >> 2;
+        const int col = ct * 32 + l31;
+        const float sc = p.sc1[col], sh = p.sh1[col];
+        const float *src = p.pc + (row0 + rt * 32 + l31) * p.cpc;
+        float a[4], b[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = c < p.cpc ? p.pc[(row0 + row) * p.cpc + c] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int col = cg * 16 + j;
-            float v = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < p.cpc) v = fmaf(x[c], W1s[c * 64 + col], v);
-            B0[row * 68 + col] = fmaxf(v * W1s[8 * 64 + col] + W1s[8 * 64 + 64 + col], 0.f);
+        for (int t = 0; t < 4; ++t) {
+            const int k = 2 * t + half;
+            a[t] = k < p.cpc ? src[k] : 0.f;
+            b[t] = k < p.cpc ? p.w1[k * 64 + col] : 0.f;
         }
+        floatx16 acc[1][1];
+        zero_acc(acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (2 * t < p.cpc) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[0][0], 0, 0, 0);
+        store_tile_lds<68>(acc[0][0], B0 + rt * 32 * 68 + ct * 32, sc, sh, l31, half);
     }
     FPN_SYNC();
 
@@ -296,9 +396,13 @@ constexpr int kTailRows = 64;
 
 __global__ __launch_bounds__(kChainThreads) void seg_tail_kernel(const SegTailParams p)
 {
-    __shared__ __attribute__((aligned(16))) float PF[kTailRows * 68];
-    __shared__ __attribute__((aligned(16))) float H[kTailRows * 132];   // conv6 chunk (128 wide); later conv8's output
-    __shared__ __attribute__((aligned(16))) float A7[kTailRows * 260];  // conv7's output; later conv9's output (stride 132)
+    // R0 / R1 are re-used from phase to phase (region, row stride in words):
+    //   conv6 columns 0..255 -> R0/260, columns 256..511 -> R1/260 (so that conv7 can
+    //   still read one half while the other is being written), conv7 -> R0/260,
+    //   conv8 -> R1/132, conv9 -> R0/129 (odd stride: conv10 reads it column-wise)
+    __shared__ __attribute__((aligned(16))) float PF[kTailRows * 68];  // point_feat; later conv10's partial sums
+    __shared__ __attribute__((aligned(16))) float R0[kTailRows * 260];
+    __shared__ __attribute__((aligned(16))) float R1[kTailRows * 260];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     FPN_KERNEL_BEGIN
@@ -306,11 +410,11 @@ __global__ __launch_bounds__(kChainThreads) void seg_tail_kernel(const SegTailPa
     const long row0 = (long)blockIdx.x * kTailRows;
     const long frustum = row0 / p.n;
 
-    const int rt = w & 1, ct = w >> 1;  // tile of a 64 x 128 output (conv6 chunk, conv8, conv9)
+    const int rt = w & 1, ct = w >> 1;  // tile of a 64 x 128 output (conv8, conv9)
     // first weight block of every product is requested one phase early (wq = the
-    // block for the next 1-tile product, wq7 = for the next conv7 partial product)
+    // block for the next conv6 / conv8 / conv9 product, wq7 = for the next conv7 one)
     WBlock wq, wq7;
-    load_wblock(wq, wtile(p.w6, ct, 2), 0, lane);
+    load_wblock(wq, wtile(p.w6, w, 2), 0, lane);
 
     // point_feat tile -> LDS
 #pragma unroll
@@ -325,75 +429,81 @@ __global__ __launch_bounds__(kChainThreads) void seg_tail_kernel(const SegTailPa
     floatx16 acc7[2][1];
     zero_acc(acc7);
     const float4 *w7t = wtile(p.w7, w, 16);  // conv7: wave w owns output columns [32 w, 32 w + 32)
-#pragma unroll 1
-    for (int kc = 0; kc < 4; ++kc) {
-        // conv6, output columns [128 kc, 128 kc + 128): PF -> H
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        float *H = kc ? R1 : R0;
+        // conv6, output columns [256 kc, 256 kc + 256): wave w owns column tile w of
+        // the chunk and both row tiles
         {
-            const int col = kc * 128 + ct * 32 + l31;
+            const int col = kc * 256 + w * 32 + l31;
             // epilogue constants are requested before the product, not after it
             const float g = p.gbias[frustum * 512 + col], sc = p.sc6[col], sh = p.sh6[col];
-            floatx16 acc[1][1];
+            floatx16 acc[2][1];
             zero_acc(acc);
-            wave_gemm<1, 2, 68>(acc, PF + (rt * 32 + l31) * 68 + 16 * half, wtile(p.w6, kc * 4 + ct, 2), lane, wq);
-            load_wblock(wq7, w7t, kc * 4, lane);
+            wave_gemm<2, 2, 68>(acc, PF + l31 * 68 + 16 * half, wtile(p.w6, kc * 8 + w, 2), lane, wq);
+            load_wblock(wq7, w7t, kc * 8, lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                H[(rt * 32 + acc_row(r, half)) * 132 + ct * 32 + l31] = fmaxf((acc[0][0][r] + g) * sc + sh, 0.f);
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    H[(a * 32 + acc_row(r, half)) * 260 + w * 32 + l31] = fmaxf((acc[a][0][r] + g) * sc + sh, 0.f);
         }
         FPN_SYNC();
-        // conv7 += H . W7[128 kc : 128 kc + 128, :]  (k-blocks 4 kc .. 4 kc + 3 of the tile)
-        wave_gemm<2, 4, 132>(acc7, H + l31 * 132 + 16 * half, w7t + (size_t)kc * 4 * 256, lane, wq7);
-        if (kc < 3) load_wblock(wq, wtile(p.w6, (kc + 1) * 4 + ct, 2), 0, lane);
+        // conv7 += H . W7[256 kc : 256 kc + 256, :]  (k-blocks 8 kc .. 8 kc + 7 of the tile)
+        wave_gemm<2, 8, 260>(acc7, H + l31 * 260 + 16 * half, w7t + (size_t)kc * 8 * 256, lane, wq7);
+        if (kc == 0) load_wblock(wq, wtile(p.w6, 8 + w, 2), 0, lane);
         else load_wblock(wq, wtile(p.w8, ct, 8), 0, lane);
-        FPN_SYNC();
+        // no barrier here: the next conv6 chunk goes to the other region
     }
-    {
+    {   // every wave passed the barrier of kc = 1 after its conv7 part of kc = 0: R0 is free
         const int col = w * 32 + l31;
         const float sc = p.sc7[col], sh = p.sh7[col];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) store_tile_lds<260>(acc7[a][0], A7 + a * 32 * 260 + w * 32, sc, sh, l31, half);
+        for (int a = 0; a < 2; ++a) store_tile_lds<260>(acc7[a][0], R0 + a * 32 * 260 + w * 32, sc, sh, l31, half);
     }
     FPN_SYNC();
-    // conv8: A7 -> H (stride 132)
+    // conv8: R0/260 -> R1/132
     {
         const int col = ct * 32 + l31;
         const float sc = p.sc8[col], sh = p.sh8[col];
         floatx16 acc[1][1];
         zero_acc(acc);
-        wave_gemm<1, 8, 260>(acc, A7 + (rt * 32 + l31) * 260 + 16 * half, wtile(p.w8, ct, 8), lane, wq);
+        wave_gemm<1, 8, 260>(acc, R0 + (rt * 32 + l31) * 260 + 16 * half, wtile(p.w8, ct, 8), lane, wq);
         load_wblock(wq, wtile(p.w9, ct, 4), 0, lane);
-        store_tile_lds<132>(acc[0][0], H + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
+        store_tile_lds<132>(acc[0][0], R1 + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
     }
     FPN_SYNC();
-    // conv9: H -> A7 region (stride 132)
-    float *A9 = A7;
+    // conv9: R1/132 -> R0/129
     {
         const int col = ct * 32 + l31;
         const float sc = p.sc9[col], sh = p.sh9[col];
         floatx16 acc[1][1];
         zero_acc(acc);
-        wave_gemm<1, 4, 132>(acc, H + (rt * 32 + l31) * 132 + 16 * half, wtile(p.w9, ct, 4), lane, wq);
-        store_tile_lds<132>(acc[0][0], A9 + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
+        wave_gemm<1, 4, 132>(acc, R1 + (rt * 32 + l31) * 132 + 16 * half, wtile(p.w9, ct, 4), lane, wq);
+        store_tile_lds<129>(acc[0][0], R0 + rt * 32 * 129 + ct * 32, sc, sh, l31, half);
     }
     FPN_SYNC();
-    // conv10 (128 -> 2, no batch norm, no activation) on the vector ALU: 8 lanes per point
+    // conv10 (128 -> 2, no batch norm, no activation) on the vector ALU: lane = point,
+    // wave w sums input channels [16 w, 16 w + 16) (wave-uniform weights), then the 8
+    // partial sums of a point meet in LDS
+    float *red = PF;
     {
-        const int row = tid >> 3, part = tid & 7;
+        const int k0 = __builtin_amdgcn_readfirstlane(w) * 16;
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int k = part * 16 + j;
-            const float a = A9[row * 132 + k];
-            s0 = fmaf(a, p.w10[k * 2 + 0], s0);
-            s1 = fmaf(a, p.w10[k * 2 + 1], s1);
+            const float a = R0[lane * 129 + k0 + j];
+            s0 = fmaf(a, p.w10[(k0 + j) * 2 + 0], s0);
+            s1 = fmaf(a, p.w10[(k0 + j) * 2 + 1], s1);
         }
+        *reinterpret_cast<float2 *>(red + (w * 64 + lane) * 2) = make_float2(s0, s1);
+    }
+    FPN_SYNC();
+    if (tid < 2 * kTailRows) {   // tid = 2 * point + output
+        float s = p.b10[tid & 1];
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            s0 += __shfl_xor(s0, off);
-            s1 += __shfl_xor(s1, off);
-        }
-        if (part == 0)
-            *reinterpret_cast<float2 *>(p.logits + (row0 + row) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
+        for (int q = 0; q < 8; ++q) s += red[q * 128 + tid];
+        p.logits[row0 * 2 + tid] = s;
     }
     FPN_KERNEL_END
 }
@@ -425,7 +535,6 @@ __global__ __launch_bounds__(kChainThreads) void obj_chain_kernel(const ObjChain
     __shared__ __attribute__((aligned(16))) float A[kObjRows * 132];
     __shared__ __attribute__((aligned(16))) float B[kObjRows * 132];
     __shared__ __attribute__((aligned(16))) float C[BOX ? kObjRows * 260 : 4];
-    __shared__ float W1s[3 * 128 + 256];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     FPN_KERNEL_BEGIN
@@ -435,26 +544,25 @@ __global__ __launch_bounds__(kChainThreads) void obj_chain_kernel(const ObjChain
     WBlock wq;  // first weight block of the next product, requested one phase early
     load_wblock(wq, wtile(p.w2, w >> 1, 4), 0, lane);
 
-    if (tid < 3 * 128) W1s[tid] = p.w1[tid];
-    if (tid < 128) {
-        W1s[3 * 128 + tid] = p.sc1[tid];
-        W1s[3 * 128 + 128 + tid] = p.sh1[tid];
-    }
-    FPN_SYNC();
-    {   // layer 1 (K = 3) on the vector ALU: 8 lanes per point, 16 columns each
-        const int row = tid >> 3, cg = tid & 7;
-        const float *src = p.obj + (row0 + row) * 3;
-        float x0 = src[0], x1 = src[1], x2 = src[2];
-        if (p.delta) {
-            const float *d = p.delta + (row0 / p.m) * 3;
-            x0 -= d[0]; x1 -= d[1]; x2 -= d[2];
-        }
+    {   // layer 1 (K = 3, zero-padded to 4) on the matrix cores, operands straight from
+        // memory: step t multiplies coordinates {2t, 2t+1}; 2 row tiles x 4 column tiles
+        const int rt = w & 1, ct = w >> 1;
+        const int col = ct * 32 + l31;
+        const float sc = p.sc1[col], sh = p.sh1[col];
+        const float *src = p.obj + (row0 + rt * 32 + l31) * 3;
+        const float *d = p.delta ? p.delta + (row0 / p.m) * 3 : nullptr;
+        float a[2], b[2];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int col = cg * 16 + j;
-            float v = fmaf(x2, W1s[256 + col], fmaf(x1, W1s[128 + col], x0 * W1s[col]));
-            A[row * 132 + col] = fmaxf(v * W1s[3 * 128 + col] + W1s[3 * 128 + 128 + col], 0.f);
+        for (int t = 0; t < 2; ++t) {
+            const int k = 2 * t + half;
+            a[t] = k < 3 ? src[k] - (d ? d[k] : 0.f) : 0.f;
+            b[t] = k < 3 ? p.w1[k * 128 + col] : 0.f;
         }
+        floatx16 acc[1][1];
+        zero_acc(acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[0][0], 0, 0, 0);
+        store_tile_lds<132>(acc[0][0], A + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
     }
     FPN_SYNC();
     {   // layer 2: A -> B, 2 row tiles x 4 column tiles

@@ -56,7 +56,7 @@ int main(int argc, char **argv)
                              dev_random(128 * 2, .1f),    dev_random(2, .1f)};
     for (int it = 0; it < 3; ++it) fpn_v1_seg_tail_f32(rows, n, pf, gb, tail, logits, nullptr);
     hipDeviceSynchronize();
-    report("seg_tail (8 waves, 64 rows)", rows / 64, 26, 8);   // begin + 12 barriers x 2 + end
+    report("seg_tail (8 waves, 64 rows)", rows / 64, 16, 8);   // begin + 7 barriers x 2 + end
 
     float *pc = dev_random(rows * 4, 10.f), *pfo, *part;
     hipMalloc(&pfo, rows * 64 * 4);
@@ -68,6 +68,6 @@ int main(int argc, char **argv)
                              dev_random(128 * 1024, .1f), dev_random(1024, 1.f), dev_random(1024, .1f)};
     for (int it = 0; it < 3; ++it) fpn_v1_seg_head_f32(rows, n, 4, pc, head, pfo, part, nullptr);
     hipDeviceSynchronize();
-    report("seg_head (8 waves, 128 rows)", rows / 128, 12, 8);  // begin + 5 barriers x 2 + end
+    report("seg_head (8 waves, 128 rows)", rows / 128, 10, 8);  // begin + 4 barriers x 2 + end
     return 0;
 }
