@@ -149,8 +149,11 @@ __device__ __forceinline__ void mfma_block(floatx16 (&acc)[TM][1], const float *
 // the scheduler sinks the loads to just before their use.  Loads past the end are
 // clamped to the last block (harmless re-reads) so that the loop body is one basic
 // block.  FPN_CHAIN_PIPELINE 0: plain form, scheduling left to the compiler.
+// Measured on MI355X (1024 frustums x 1024 points): 128.2k frustums/s pipelined,
+// 130.7k plain - with two waves per SIMD the other wave already covers the load
+// latency, and what is lost is lost at the phase boundaries, not inside this loop.
 #ifndef FPN_CHAIN_PIPELINE
-#define FPN_CHAIN_PIPELINE 1
+#define FPN_CHAIN_PIPELINE 0
 #endif
 
 template <int TM>

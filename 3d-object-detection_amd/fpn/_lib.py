@@ -51,6 +51,8 @@ SIGNATURES = {
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],
+    "fpn_box3d_iou_f64": [_l, _vp, _l, _vp, _l, _vp, _vp],
+    "fpn_box3d_best_overlap_f64": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_mask_gather": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 

@@ -313,6 +313,33 @@ int fpn_mask_gather(int b, int n, int cpc, int npick, const float *point_cloud,
                     void *stream);
 
 /*
+ * 3-D IoU of box pairs as the detection evaluation defines it:
+ * Box3D.get_iou (helpers/mAP_evaluation.py:176-182) = clip(I / (Va + Vb - I), 0, 1)
+ * with I = overlap of the height intervals (:156-160) x area of the intersection
+ * of the two ground rectangles (:162-174), the rectangles built from
+ * rotation_matrix[0,0] and [0,1] of the box's quaternion (:117-132) and
+ * V = width*length*height (:79).  All arithmetic in float64.
+ *   A box is 10 doubles: translation x,y,z; size width,length,height; rotation
+ *   quaternion w,x,y,z (the field order of the evaluation's dictionaries, :10-16).
+ *   iou[i] = IoU(a + i*stride_a, b + i*stride_b), i < n; a stride of 0 compares
+ *   every box of the other array with one box (get_ious, :259-260), otherwise
+ *   strides are in doubles and >= 10.
+ */
+int fpn_box3d_iou_f64(long n, const double *a, long stride_a, const double *b, long stride_b,
+                      double *iou, void *stream);
+
+/*
+ * The inner search of recall_precision (helpers/mAP_evaluation.py:282-297) for all
+ * predictions at once: prediction i is compared with the gt_count[i] ground-truth
+ * boxes gt[gt_begin[i] ...] of its own sample; best_iou[i] = the largest IoU,
+ * best_j[i] = its index within that range (the first one on ties, as np.argmax);
+ * gt_count[i] == 0 gives -inf and -1 (:282-283).  pred (npred,10), gt (*,10).
+ */
+int fpn_box3d_best_overlap_f64(int npred, const double *pred, const double *gt,
+                               const int *gt_begin, const int *gt_count, double *best_iou,
+                               int *best_j, void *stream);
+
+/*
  * Monte-Carlo ensemble statistics over S sampled forward passes of the Bayesian
  * detector (the reference produces the samples with repeated `predict` calls of
  * models/FPointNet_Bayes.py's det_model and holds no code for the statistics; the
