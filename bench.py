@@ -97,6 +97,27 @@ def cpu_baseline(seconds=12.0):
 
 PEAK_HBM_GBS = 8000.0   # MI355X HBM3E spec peak, GB/s
 
+# observer name of a launch -> kernel name in the rocprofv3 counter summaries
+PMC_KERNEL = {"v1_seg_tail": "seg_tail_kernel", "v1_seg_head": "seg_head_kernel",
+              "v1_obj_chain_box": "obj_chain_kernel<true>", "v1_obj_chain_tnet": "obj_chain_kernel<false>"}
+
+
+def measured_traffic(name, batch, points):
+    """HBM bytes per launch of kernel `name` from the newest committed rocprofv3 PMC
+    summary (profiles/*_pmc_traffic.json, made by tools/pmc_summary.py from separate
+    FETCH_SIZE and WRITE_SIZE passes over this same command at the default workload).
+    Counters cannot be read from inside the timed process, so this is a recorded
+    measurement; None when there is no summary or the workload is not the default."""
+    import glob
+    if (batch, points) != (1024, 1024) or name not in PMC_KERNEL:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"].get(PMC_KERNEL[name])
+    return (k["hbm_bytes_per_launch"], os.path.basename(files[-1])) if k else (None, None)
+
 
 def pointset_ops(dev, frustums=256, reps=20):
     """Achieved HBM GB/s of the point-set operators at the v2 shapes (2048 points per
@@ -226,8 +247,10 @@ def main():
             name = max(agg, key=lambda k: agg[k][2])
             launches, flops, secs = agg[name]
             ach = flops / secs / 1e12
+            traffic, traffic_src = measured_traffic(name, b_local, args.points) if not args.chunk else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": name,
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_source": traffic_src, "kernel": name,
                                "launches": launches, "avg_launch_ms": secs / launches * 1e3,
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,
                                "share_of_step_time": secs / dt}
