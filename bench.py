@@ -159,6 +159,94 @@ def pointset_ops(dev, frustums=256, reps=20):
     return out
 
 
+def side_config(args):
+    """The other GPU workloads BASELINE names, with the same timing protocol as the
+    headline one: --config v2 (PointNet++ variant: FPS + ball query + grouping + shared
+    MLPs + 3-NN interpolation, 2048 points) and --config bayes (Flipout v1, S sampled
+    passes per frustum + ensemble statistics).  One JSON line, no roofline object: these
+    are mixes of HBM-bound point-set kernels and MFMA layers, the per-operator
+    bandwidths are in the `pointset_ops` table of the default run."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from fpn import dist as fdist
+    from fpn import synthetic, variables
+    if args.config == "v2":
+        from fpn.models import frustum_pointnets_v2 as M2
+        b_local = args.batch if args.batch != 1024 else 256
+        points = args.points if args.points != 1024 else 2048
+        pc_np, oh_np = synthetic.make_frustums(b_local, points, 4, seed=rank)
+        pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
+        st = variables.VariableStore(dev, seed=1)
+        with variables.use_store(st):
+            M2.get_model(pc[:2], one_hot[:2], False)      # creates the variables
+        st.randomize_batch_norm(2)
+
+        def step():
+            with variables.use_store(st):
+                return fdist.pack_results(M2.get_model(pc, one_hot, False))
+        label = "Frustum PointNet v2 (SA-MSG x2, SA, FP x3; box net SA x3) inference, %d frustums x %d pts x 4 ch " \
+                "per GPU, fp32" % (b_local, points)
+        metric = "frustums/sec (node) FPointNet v2 N=%d" % points
+    else:
+        from fpn import bayes, uncertainty
+        b_local = args.batch if args.batch != 1024 else 128
+        points = args.points
+        pc_np, oh_np = synthetic.make_frustums(b_local, points, 3, seed=rank)
+        pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
+        st = variables.VariableStore(dev, seed=1)
+        bayes.init_variables(st, 3)
+        bp = bayes.BayesPlan(st, 3)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(7 + rank)
+
+        def step():
+            ep = bp.forward(pc, one_hot, args.samples, generator=gen)
+            return uncertainty.mc_statistics(ep["box_output"], ep["stage1_center"])
+        label = "Flipout Frustum PointNet v1, %d Monte-Carlo samples x %d frustums x %d pts per GPU, fp32, " \
+                "ensemble statistics on device" % (args.samples, b_local, points)
+        metric = "frustums/sec (node) FPointNet Bayes S=%d N=%d" % (args.samples, points)
+    gathered = None
+
+    def full_step():
+        nonlocal gathered
+        rec = step()
+        if world > 1:
+            if gathered is None:
+                gathered = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, rec.contiguous())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        full_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": metric, "value": world * b_local * args.steps / dt, "unit": "frustums/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": label, "frustums_per_gpu": b_local, "points": points}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +258,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-pointset", action="store_true", help="skip the point-set operator bandwidth table")
+    ap.add_argument("--config", choices=("v1", "v2", "bayes"), default="v1",
+                    help="v1: BASELINE config 1 (the headline metric, default); v2: PointNet++ variant, 2048 points "
+                         "(config 2); bayes: Flipout v1 with --samples Monte-Carlo passes per frustum (config 3)")
+    ap.add_argument("--samples", type=int, default=32, help="Monte-Carlo samples per frustum (--config bayes)")
     args = ap.parse_args()
+    if args.config != "v1":
+        return side_config(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
