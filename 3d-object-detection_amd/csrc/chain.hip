@@ -4,8 +4,6 @@
 //
 //   seg head  : conv1 -> conv2 -> conv3 (point_feat, also stored) -> conv4 ->
 //               conv5 + max over points                 128 points per workgroup
-//   seg tail  : conv6 (point part + per-frustum bias) -> conv7 -> conv8 -> conv9
-//               -> conv10                                64 points per workgroup
 //   obj chain : T-Net / box-net convolution stacks + max  64 object points per workgroup
 //
 // Matrix work runs on v_mfma_f32_32x32x2_f32 (exact fp32).  One MFMA multiplies, for
@@ -380,138 +378,6 @@ __global__ __launch_bounds__(kChainThreads) void seg_head_kernel(const SegHeadPa
 }
 
 // ---------------------------------------------------------------------------
-// seg tail
-// ---------------------------------------------------------------------------
-struct SegTailParams {
-    long rows;
-    int n;  // points per frustum (multiple of 64)
-    const float *point_feat;  // (rows,64)
-    const float *gbias;       // (rows/n,512): [global_feat | one_hot] . W6[64:]
-    const float *w6, *sc6, *sh6;  // (64,512)  point rows of conv6, tiled
-    const float *w7, *sc7, *sh7;  // (512,256) tiled
-    const float *w8, *sc8, *sh8;  // (256,128) tiled
-    const float *w9, *sc9, *sh9;  // (128,128) tiled
-    const float *w10, *b10;       // (128,2) plain, (2)
-    float *logits;                // (rows,2)
-};
-
-constexpr int kTailRows = 64;
-
-__global__ __launch_bounds__(kChainThreads) void seg_tail_kernel(const SegTailParams p)
-{
-    // R0 / R1 are re-used from phase to phase (region, row stride in words):
-    //   conv6 columns 0..255 -> R0/260, columns 256..511 -> R1/260 (so that conv7 can
-    //   still read one half while the other is being written), conv7 -> R0/260,
-    //   conv8 -> R1/132, conv9 -> R0/129 (odd stride: conv10 reads it column-wise)
-    __shared__ __attribute__((aligned(16))) float PF[kTailRows * 68];  // point_feat; later conv10's partial sums
-    __shared__ __attribute__((aligned(16))) float R0[kTailRows * 260];
-    __shared__ __attribute__((aligned(16))) float R1[kTailRows * 260];
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    FPN_KERNEL_BEGIN
-    const int l31 = lane & 31, half = lane >> 5;
-    const long row0 = (long)blockIdx.x * kTailRows;
-    const long frustum = row0 / p.n;
-
-    const int rt = w & 1, ct = w >> 1;  // tile of a 64 x 128 output (conv8, conv9)
-    // first weight block of every product is requested one phase early (wq = the
-    // block for the next conv6 / conv8 / conv9 product, wq7 = for the next conv7 one)
-    WBlock wq, wq7;
-    load_wblock(wq, wtile(p.w6, w, 2), 0, lane);
-
-    // point_feat tile -> LDS
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + kChainThreads * i;
-        const int row = e >> 4, q = e & 15;
-        *reinterpret_cast<float4 *>(PF + row * 68 + 4 * q) =
-            *reinterpret_cast<const float4 *>(p.point_feat + (row0 + row) * 64 + 4 * q);
-    }
-    FPN_SYNC();
-
-    floatx16 acc7[2][1];
-    zero_acc(acc7);
-    const float4 *w7t = wtile(p.w7, w, 16);  // conv7: wave w owns output columns [32 w, 32 w + 32)
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-        float *H = kc ? R1 : R0;
-        // conv6, output columns [256 kc, 256 kc + 256): wave w owns column tile w of
-        // the chunk and both row tiles
-        {
-            const int col = kc * 256 + w * 32 + l31;
-            // epilogue constants are requested before the product, not after it
-            const float g = p.gbias[frustum * 512 + col], sc = p.sc6[col], sh = p.sh6[col];
-            floatx16 acc[2][1];
-            zero_acc(acc);
-            wave_gemm<2, 2, 68>(acc, PF + l31 * 68 + 16 * half, wtile(p.w6, kc * 8 + w, 2), lane, wq);
-            load_wblock(wq7, w7t, kc * 8, lane);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    H[(a * 32 + acc_row(r, half)) * 260 + w * 32 + l31] = fmaxf((acc[a][0][r] + g) * sc + sh, 0.f);
-        }
-        FPN_SYNC();
-        // conv7 += H . W7[256 kc : 256 kc + 256, :]  (k-blocks 8 kc .. 8 kc + 7 of the tile)
-        wave_gemm<2, 8, 260>(acc7, H + l31 * 260 + 16 * half, w7t + (size_t)kc * 8 * 256, lane, wq7);
-        if (kc == 0) load_wblock(wq, wtile(p.w6, 8 + w, 2), 0, lane);
-        else load_wblock(wq, wtile(p.w8, ct, 8), 0, lane);
-        // no barrier here: the next conv6 chunk goes to the other region
-    }
-    {   // every wave passed the barrier of kc = 1 after its conv7 part of kc = 0: R0 is free
-        const int col = w * 32 + l31;
-        const float sc = p.sc7[col], sh = p.sh7[col];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) store_tile_lds<260>(acc7[a][0], R0 + a * 32 * 260 + w * 32, sc, sh, l31, half);
-    }
-    FPN_SYNC();
-    // conv8: R0/260 -> R1/132
-    {
-        const int col = ct * 32 + l31;
-        const float sc = p.sc8[col], sh = p.sh8[col];
-        floatx16 acc[1][1];
-        zero_acc(acc);
-        wave_gemm<1, 8, 260>(acc, R0 + (rt * 32 + l31) * 260 + 16 * half, wtile(p.w8, ct, 8), lane, wq);
-        load_wblock(wq, wtile(p.w9, ct, 4), 0, lane);
-        store_tile_lds<132>(acc[0][0], R1 + rt * 32 * 132 + ct * 32, sc, sh, l31, half);
-    }
-    FPN_SYNC();
-    // conv9: R1/132 -> R0/129
-    {
-        const int col = ct * 32 + l31;
-        const float sc = p.sc9[col], sh = p.sh9[col];
-        floatx16 acc[1][1];
-        zero_acc(acc);
-        wave_gemm<1, 4, 132>(acc, R1 + (rt * 32 + l31) * 132 + 16 * half, wtile(p.w9, ct, 4), lane, wq);
-        store_tile_lds<129>(acc[0][0], R0 + rt * 32 * 129 + ct * 32, sc, sh, l31, half);
-    }
-    FPN_SYNC();
-    // conv10 (128 -> 2, no batch norm, no activation) on the vector ALU: lane = point,
-    // wave w sums input channels [16 w, 16 w + 16) (wave-uniform weights), then the 8
-    // partial sums of a point meet in LDS
-    float *red = PF;
-    {
-        const int k0 = __builtin_amdgcn_readfirstlane(w) * 16;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float a = R0[lane * 129 + k0 + j];
-            s0 = fmaf(a, p.w10[(k0 + j) * 2 + 0], s0);
-            s1 = fmaf(a, p.w10[(k0 + j) * 2 + 1], s1);
-        }
-        *reinterpret_cast<float2 *>(red + (w * 64 + lane) * 2) = make_float2(s0, s1);
-    }
-    FPN_SYNC();
-    if (tid < 2 * kTailRows) {   // tid = 2 * point + output
-        float s = p.b10[tid & 1];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += red[q * 128 + tid];
-        p.logits[row0 * 2 + tid] = s;
-    }
-    FPN_KERNEL_END
-}
-
-// ---------------------------------------------------------------------------
 // Object-point chains: the convolution stacks of the T-Net (3 -> 128 -> 128 ->
 // 256, max over points) and of the box net (3 -> 128 -> 128 -> 256 -> 512, max
 // over points), 64 object points per workgroup.  The box net's input is the
@@ -674,26 +540,6 @@ int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float 
     p.point_feat = point_feat; p.partial = partial_max;
     hipLaunchKernelGGL(seg_head_kernel, dim3((unsigned)(rows / kHeadRows)), dim3(kChainThreads), 0, as_stream(stream), p);
     return check_launch("fpn_v1_seg_head_f32");
-}
-
-int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_bias,
-                        const float *const *layers, float *logits, void *stream)
-{
-    FPN_REQUIRE(rows >= 0 && n >= 1, "v1_seg_tail: bad size");
-    FPN_REQUIRE(n % kTailRows == 0 && rows % n == 0, "v1_seg_tail: points per frustum (%d) must be a multiple of %d", n, kTailRows);
-    if (rows == 0) return FPN_OK;
-    FPN_REQUIRE(point_feat && group_bias && layers && logits, "v1_seg_tail: null pointer");
-    for (int i = 0; i < 14; ++i) FPN_REQUIRE(layers[i], "v1_seg_tail: layer parameter %d is null", i);
-    SegTailParams p{};
-    p.rows = rows; p.n = n; p.point_feat = point_feat; p.gbias = group_bias;
-    p.w6 = layers[0]; p.sc6 = layers[1]; p.sh6 = layers[2];
-    p.w7 = layers[3]; p.sc7 = layers[4]; p.sh7 = layers[5];
-    p.w8 = layers[6]; p.sc8 = layers[7]; p.sh8 = layers[8];
-    p.w9 = layers[9]; p.sc9 = layers[10]; p.sh9 = layers[11];
-    p.w10 = layers[12]; p.b10 = layers[13];
-    p.logits = logits;
-    hipLaunchKernelGGL(seg_tail_kernel, dim3((unsigned)(rows / kTailRows)), dim3(kChainThreads), 0, as_stream(stream), p);
-    return check_launch("fpn_v1_seg_tail_f32");
 }
 
 // rows of partial_max per workgroup: which = 0 seg head, 1 object chains

@@ -1,0 +1,402 @@
+// Register-resident layer chains: a WAVE carries 32 points through consecutive
+// shared-MLP layers with every activation in registers - no LDS, no barriers.
+//
+// The trick is to compute each layer TRANSPOSED, Y^T = W^T . X^T, on
+// v_mfma_f32_32x32x2_f32:
+//   A operand (32 x 2) = W^T tile: lane l supplies W[k(l>>5)][32 t + (l&31)]   (weights)
+//   B operand (2 x 32) = X^T     : lane l supplies X[point l&31][k(l>>5)]      (activations)
+//   D (32 x 32)        = Y^T tile: lane l, register r holds
+//                        Y[point l&31][32 t + (r&3) + 8 (r>>2) + 4 (l>>5)]
+// so after the layer lane (p, h) owns, for point p, the 16 channels 8q + 4h + i
+// (r = 4q + i) of every 32-channel tile - and that is exactly the shape of a B
+// operand: register r of tile j can be fed to the next layer's MFMA as "k-step (j, r)",
+// in which the lower lane half contributes channel 32j + 8q + i and the upper half
+// channel 32j + 8q + 4 + i.  The matching weight rows are baked into the weight
+// layout (fpn_tile_weights_reg_f32), so the only per-MFMA operand traffic is one
+// weight register per lane, streamed from L2 as coalesced 16-byte loads two chunks
+// (32 MFMAs) ahead.  Bias / batch norm / ReLU run on the accumulator registers in
+// place, in the issue shadow of the next tile's MFMAs.
+//
+// The kernel is written as a sequence of DOUBLE STEPS of 32 MFMAs: one activation tile
+// against two output tiles (two weight chunks, MFMAs alternating between the two
+// accumulators).  Each double step also requests the two weight chunks of the next one
+// and may carry the epilogue of an earlier tile and the loads of its constants.  Steps
+// are fenced (sched_barrier) and the order inside a step is pinned with
+// sched_group_barrier - one load and a few vector-ALU operations after each MFMA -
+// because with one wave per SIMD (the activations of 32 points through 512 -> 256
+// channels need ~400 registers) nothing else hides a misplaced wait.
+//
+// Measured on MI355X, seg tail of 1024 frustums x 1024 points: 3.16 ms = 141.7 TFLOP/s
+// (90 % of the fp32 MFMA peak) against 3.49 ms for the LDS-resident version of the same
+// chain that this replaced (8 waves sharing a 64-point tile, 7 barriers per tile).
+#include <algorithm>
+#include <cstdint>
+#include <type_traits>
+#include <utility>
+
+#include "fpn_common.h"
+
+namespace fpn {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// Waves per workgroup: one per SIMD.  The four waves of a workgroup start together and
+// run the same instruction stream, so they ask for the same weight chunk at nearly the
+// same time and three of the four requests hit in the CU's L1.
+constexpr int kRegWaves = 4;
+
+// Optional phase time stamps (diagnostic builds only, -DFPN_REG_STAMPS; read back by
+// tools/tail_reg_stamps.hip).  Compiled out of the library.
+#ifdef FPN_REG_STAMPS
+__device__ unsigned long long g_reg_stamps[1 << 20];
+#define FPN_STAMP(i)                                                                           \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if ((threadIdx.x & 63) == 0)                                                           \
+            g_reg_stamps[((size_t)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define FPN_STAMP(i)
+#endif
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(std::forward<F>(f));
+    }
+}
+
+struct WChunk {          // the 16 weights of a lane for the 16 MFMA steps of one
+    float4 q[4];         // (output tile, input tile) pair: step r = 4q + i
+};
+
+__device__ __forceinline__ float comp(const float4 &v, int i)
+{
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+#ifdef FPN_REG_SAMEADDR   // diagnostic: every chunk read goes to one 4 KiB block (always in L1)
+__constant__ const float4 *g_same_chunk;
+#endif
+
+__device__ __forceinline__ void load_chunk(WChunk &c, const float4 *__restrict__ p, unsigned lane)
+{
+#ifdef FPN_REG_SAMEADDR
+    p = g_same_chunk;
+#endif
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.q[q] = p[q * 64 + lane];
+}
+
+// acc(out tile, points) += W chunk x activation tile: 16 MFMA steps
+__device__ __forceinline__ void mfma16(floatx16 &acc, const WChunk &w, const floatx16 &act)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(w.q[r >> 2], r & 3), act[r], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void zero(floatx16 &a)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// per-channel constants of a lane for one 32-channel tile: channels ch0 + 8q + i
+struct TileConst {
+    float4 q[4];
+};
+
+__device__ __forceinline__ void load_const(TileConst &c, const float *__restrict__ p, int ch0)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.q[q] = *reinterpret_cast<const float4 *>(p + ch0 + 8 * q);
+}
+
+// a = relu(a * sc + sh) in place
+__device__ __forceinline__ void bn_relu(floatx16 &a, const TileConst &sc, const TileConst &sh)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r] * comp(sc.q[r >> 2], r & 3) + comp(sh.q[r >> 2], r & 3), 0.f);
+}
+
+// Order of one step of NMFMA MFMAs: after each MFMA one memory read (while there are
+// any, NVMEM of them) and NVALU vector-ALU operations; nothing crosses the step's end.
+template <int NMFMA, int NVMEM, int NVALU>
+__device__ __forceinline__ void sched_step()
+{
+#pragma unroll
+    for (int m = 0; m < NMFMA; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+        if (m < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
+        if (NVALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);    // VALU
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Two output tiles against one activation tile, MFMAs alternating between the two
+// accumulators so that consecutive MFMAs are independent: 32 MFMA steps.
+__device__ __forceinline__ void mfma_pair(floatx16 &acc_a, floatx16 &acc_b, const WChunk &wa, const WChunk &wb,
+                                          const floatx16 &act)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(wa.q[r >> 2], r & 3), act[r], acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(wb.q[r >> 2], r & 3), act[r], acc_b, 0, 0, 0);
+    }
+}
+
+struct SegTailRegParams {
+    long rows;
+    int n;
+    const float *point_feat;      // (rows,64)
+    const float *gshift;          // (rows/n,512): conv6's shift with the frustum part folded in
+    const float4 *w6;             // chunk (t, j) at (t*2 + j) * 256 float4
+    const float *sc6;
+    const float4 *w7;             // chunk (t, j) at (t*16 + j) * 256
+    const float *sc7, *sh7;
+    const float4 *w8;             // chunk (j, t) at (j*4 + t) * 256
+    const float *sc8, *sh8;
+    const float4 *w9;             // chunk (j, t) at (j*4 + t) * 256
+    const float *sc9, *sh9;
+    const float *w10, *b10;       // (128,2) row-major, (2)
+    float *logits;                // (rows,2)
+};
+
+// The loop body of conv6-chunk kc / conv7-partial kc is 20 double steps; double step D
+// multiplies one activation tile into the output tiles (2x, 2x+1), U selects which:
+//   D in [0,4)   conv6 output tiles 4kc + 2(D/2) + U, input tile D%2
+//   D in [4,20)  conv7 output tiles 2((D-4)/4) + U, input tile 4kc + (D-4)%4
+//   D = 20       what follows: double step 0 of kc+1, or of conv8 after kc = 3
+template <int D, int U>
+__device__ __forceinline__ const float4 *tail_body_chunk(const SegTailRegParams &p, int kc)
+{
+    if constexpr (D < 4) {
+        return p.w6 + (size_t)((4 * kc + 2 * (D >> 1) + U) * 2 + (D & 1)) * 256;
+    } else if constexpr (D < 20) {
+        return p.w7 + (size_t)((2 * ((D - 4) >> 2) + U) * 16 + 4 * kc + ((D - 4) & 3)) * 256;
+    } else {
+        const float4 *next_body = p.w6 + (size_t)((4 * (kc + 1) + U) * 2) * 256;
+        const float4 *conv8 = p.w8 + (size_t)U * 256;
+        return kc < 3 ? next_body : conv8;
+    }
+}
+
+__global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegTailRegParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;   // waves are independent (no barriers): a surplus wave just leaves
+    const long frustum = row0 / p.n;
+    const float *gs = p.gshift + frustum * 512;
+    FPN_STAMP(0);
+
+    // weight chunks of double step D live in ring[2 (D % 2)], ring[2 (D % 2) + 1];
+    // those of D + 1 are requested while D computes
+    WChunk ring[4];
+    load_chunk(ring[0], tail_body_chunk<0, 0>(p, 0), lane);
+    load_chunk(ring[1], tail_body_chunk<0, 1>(p, 0), lane);
+
+    // point_feat of this wave's 32 points, as B operands: tile j, register 4q + i =
+    // channel 32j + 8q + 4h + i
+    floatx16 pf[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(p.point_feat + (row0 + pt) * 64 + 32 * j + 8 * q + 4 * h);
+            pf[j][4 * q + 0] = v.x; pf[j][4 * q + 1] = v.y; pf[j][4 * q + 2] = v.z; pf[j][4 * q + 3] = v.w;
+        }
+
+    floatx16 acc7[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) zero(acc7[t]);
+    TileConst c7sc, c7sh;   // conv7's constants of tile 0, requested near the end of the loop
+    __builtin_amdgcn_sched_barrier(0);
+    FPN_STAMP(1);
+
+#pragma unroll 1
+    for (int kc = 0; kc < 4; ++kc) {
+        floatx16 hbuf[4];
+        TileConst csc[2], cgs[2];   // constants of the conv6 tile pair in flight
+        static_for<0, 20>([&](auto I) {
+            constexpr int D = decltype(I)::value;
+            constexpr int cur = 2 * (D & 1), nxt = 2 * ((D + 1) & 1);
+            load_chunk(ring[nxt], tail_body_chunk<D + 1, 0>(p, kc), lane);
+            load_chunk(ring[nxt + 1], tail_body_chunk<D + 1, 1>(p, kc), lane);
+            if constexpr (D == 1 || D == 3) {
+                // constants of the conv6 tile pair that this step completes; its epilogue
+                // rides on the next step
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ch0 = 128 * kc + 32 * (2 * (D >> 1) + u) + 4 * h;
+                    load_const(csc[u], p.sc6, ch0);
+                    load_const(cgs[u], gs, ch0);
+                }
+            }
+            if constexpr (D == 2 || D == 4) {   // epilogue of the pair completed by the previous step
+                bn_relu(hbuf[D - 2], csc[0], cgs[0]);
+                bn_relu(hbuf[D - 1], csc[1], cgs[1]);
+            }
+            if constexpr (D < 4) {
+                // ---- conv6 tile pair D/2 of this chunk, input tile D % 2
+                constexpr int tp = D >> 1;
+                if constexpr ((D & 1) == 0) {
+                    zero(hbuf[2 * tp]);
+                    zero(hbuf[2 * tp + 1]);
+                }
+                mfma_pair(hbuf[2 * tp], hbuf[2 * tp + 1], ring[cur], ring[cur + 1], pf[D & 1]);
+            } else {
+                // ---- conv7 += H . W7[128 kc : 128 kc + 128, :], output pair (D-4)/4, input tile (D-4)%4
+                constexpr int m = D - 4;
+                mfma_pair(acc7[2 * (m >> 2)], acc7[2 * (m >> 2) + 1], ring[cur], ring[cur + 1], hbuf[m & 3]);
+                if constexpr (D == 18) {
+                    load_const(c7sc, p.sc7, 4 * h);
+                    load_const(c7sh, p.sh7, 4 * h);
+                }
+            }
+            sched_step<32, (D == 1 || D == 3) ? 24 : (D == 18 ? 16 : 8), (D == 2 || D == 4) ? 3 : 0>();
+        });
+    }
+
+    // ---- conv8: 256 -> 128 as 16 double steps E = (input tile j = E / 2, output pair E % 2);
+    //      weight chunks 2E, 2E+1 (j-major).  conv7's batch norm + ReLU of input tile j+1
+    //      rides on step (j, 1); its constants are requested in step (j, 0).
+    FPN_STAMP(2);
+    floatx16 acc8[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) zero(acc8[t]);
+    bn_relu(acc7[0], c7sc, c7sh);
+    __builtin_amdgcn_sched_barrier(0);
+    TileConst ca, cb;
+    static_for<0, 16>([&](auto I) {
+        constexpr int E = decltype(I)::value, j = E >> 1, tp = E & 1;
+        constexpr int cur = 2 * (E & 1), nxt = 2 * ((E + 1) & 1);
+        // the step after E = 15 is conv9's first
+        load_chunk(ring[nxt], E < 15 ? p.w8 + (size_t)(2 * E + 2) * 256 : p.w9, lane);
+        load_chunk(ring[nxt + 1], E < 15 ? p.w8 + (size_t)(2 * E + 3) * 256 : p.w9 + 256, lane);
+        if constexpr (tp == 0) {
+            // next input tile of conv8, or (last j) the first input tile of conv9
+            load_const(ca, j < 7 ? p.sc7 : p.sc8, (j < 7 ? 32 * (j + 1) : 0) + 4 * h);
+            load_const(cb, j < 7 ? p.sh7 : p.sh8, (j < 7 ? 32 * (j + 1) : 0) + 4 * h);
+        } else {
+            if constexpr (j < 7) bn_relu(acc7[j + 1], ca, cb);
+            else bn_relu(acc8[0], ca, cb);      // complete since step (7, 0)
+        }
+        mfma_pair(acc8[2 * tp], acc8[2 * tp + 1], ring[cur], ring[cur + 1], acc7[j]);
+        sched_step<32, tp == 0 ? 16 : 8, tp == 0 ? 0 : 2>();
+    });
+    // ---- conv9: 128 -> 128 as 8 double steps, same scheme; conv8's epilogue of input tile
+    //      j+1 rides on step (j, 1); in the last step the epilogue of conv9's own tile 0
+    FPN_STAMP(3);
+    floatx16 acc9[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) zero(acc9[t]);
+    static_for<0, 8>([&](auto I) {
+        constexpr int F = decltype(I)::value, j = F >> 1, tp = F & 1;
+        constexpr int cur = 2 * (F & 1), nxt = 2 * ((F + 1) & 1);
+        if constexpr (F < 7) {
+            load_chunk(ring[nxt], p.w9 + (size_t)(2 * F + 2) * 256, lane);
+            load_chunk(ring[nxt + 1], p.w9 + (size_t)(2 * F + 3) * 256, lane);
+        }
+        if constexpr (tp == 0) {
+            load_const(ca, j < 3 ? p.sc8 : p.sc9, (j < 3 ? 32 * (j + 1) : 0) + 4 * h);
+            load_const(cb, j < 3 ? p.sh8 : p.sh9, (j < 3 ? 32 * (j + 1) : 0) + 4 * h);
+        } else {
+            if constexpr (j < 3) bn_relu(acc8[j + 1], ca, cb);
+            else bn_relu(acc9[0], ca, cb);      // complete since step (3, 0)
+        }
+        mfma_pair(acc9[2 * tp], acc9[2 * tp + 1], ring[cur], ring[cur + 1], acc8[j]);
+        sched_step<32, (F < 7 ? 8 : 0) + (tp == 0 ? 8 : 0), tp == 0 ? 0 : 2>();
+    });
+    // ---- rest of conv9's epilogue + conv10 (128 -> 2, plain bias) on the vector ALU
+    FPN_STAMP(4);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j > 0) {
+            TileConst sc, sh;
+            load_const(sc, p.sc9, 32 * j + 4 * h);
+            load_const(sh, p.sh9, 32 * j + 4 * h);
+            bn_relu(acc9[j], sc, sh);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 *w = reinterpret_cast<const float4 *>(p.w10 + (32 * j + 8 * q + 4 * h) * 2);
+            const float4 wa = w[0], wb = w[1];   // channels c, c+1 | c+2, c+3, two outputs each
+            s0 = fmaf(acc9[j][4 * q + 0], wa.x, s0); s1 = fmaf(acc9[j][4 * q + 0], wa.y, s1);
+            s0 = fmaf(acc9[j][4 * q + 1], wa.z, s0); s1 = fmaf(acc9[j][4 * q + 1], wa.w, s1);
+            s0 = fmaf(acc9[j][4 * q + 2], wb.x, s0); s1 = fmaf(acc9[j][4 * q + 2], wb.y, s1);
+            s0 = fmaf(acc9[j][4 * q + 3], wb.z, s0); s1 = fmaf(acc9[j][4 * q + 3], wb.w, s1);
+        }
+    }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    if (h == 0) *reinterpret_cast<float2 *>(p.logits + (row0 + pt) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
+    FPN_STAMP(5);
+}
+
+// w (cin,cout) row-major -> 4 KiB chunks for the register chains, one per
+// (32-row input tile j, 32-column output tile t):
+//   element (q, lane, i) of a chunk = w[32j + 8q + 4(lane>>5) + i][32t + (lane&31)]
+// chunk (t, j) is stored at index t*(cin/32) + j, or, j-major, at j*(cout/32) + t.
+__global__ void tile_weights_reg_kernel(int cin, int cout, int jmajor, const float *__restrict__ w, float *__restrict__ wt)
+{
+    const long total = (long)cin * cout;
+    const int nj = cin / 32, nt = cout / 32;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int i = e & 3, l = (e >> 2) & 63, q = (e >> 8) & 3;
+        const long chunk = e >> 10;
+        const int t = jmajor ? (int)(chunk % nt) : (int)(chunk / nj);
+        const int j = jmajor ? (int)(chunk / nt) : (int)(chunk % nj);
+        const int k = 32 * j + 8 * q + 4 * (l >> 5) + i, col = 32 * t + (l & 31);
+        wt[e] = w[(long)k * cout + col];
+    }
+}
+
+}  // namespace
+}  // namespace fpn
+
+using namespace fpn;
+
+extern "C" {
+
+int fpn_tile_weights_reg_f32(int cin, int cout, int jmajor, const float *w, float *w_tiled, void *stream)
+{
+    FPN_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0,
+                "tile_weights_reg: cin (%d) and cout (%d) must be multiples of 32", cin, cout);
+    FPN_REQUIRE(w && w_tiled && w != w_tiled, "tile_weights_reg: null or aliased pointer");
+    const long total = (long)cin * cout;
+    hipLaunchKernelGGL(tile_weights_reg_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       as_stream(stream), cin, cout, jmajor, w, w_tiled);
+    return check_launch("fpn_tile_weights_reg_f32");
+}
+
+int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_shift,
+                        const float *const *layers, float *logits, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && n >= 1, "v1_seg_tail: bad size");
+    FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_tail: points per frustum (%d) must be a multiple of 32", n);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(point_feat && group_shift && layers && logits, "v1_seg_tail: null pointer");
+    for (int i = 0; i < 13; ++i) FPN_REQUIRE(layers[i], "v1_seg_tail: layer parameter %d is null", i);
+    SegTailRegParams p{};
+    p.rows = rows; p.n = n; p.point_feat = point_feat; p.gshift = group_shift;
+    p.w6 = reinterpret_cast<const float4 *>(layers[0]); p.sc6 = layers[1];
+    p.w7 = reinterpret_cast<const float4 *>(layers[2]); p.sc7 = layers[3]; p.sh7 = layers[4];
+    p.w8 = reinterpret_cast<const float4 *>(layers[5]); p.sc8 = layers[6]; p.sh8 = layers[7];
+    p.w9 = reinterpret_cast<const float4 *>(layers[8]); p.sc9 = layers[9]; p.sh9 = layers[10];
+    p.w10 = layers[11]; p.b10 = layers[12];
+    p.logits = logits;
+    const long waves = rows / 32;
+    hipLaunchKernelGGL(seg_tail_reg_kernel, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
+                       as_stream(stream), p);
+    return check_launch("fpn_v1_seg_tail_f32");
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpn_hip.so")
 
 FPN_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FpnError(RuntimeError):
@@ -46,6 +46,7 @@ SIGNATURES = {
                                    _vp, _i, _vp, _sz, _vp],
     "fpn_max_pool_rows": [_l, _i, _i, _vp, _i, _vp, _i, _vp],
     "fpn_tile_weights_f32": [_i, _i, _vp, _vp, _vp],
+    "fpn_tile_weights_reg_f32": [_i, _i, _i, _vp, _vp, _vp],
     "fpn_v1_chain_rows": [_i],
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],

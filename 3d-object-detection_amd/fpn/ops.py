@@ -123,6 +123,18 @@ def tile_weights(w):
     return out
 
 
+def tile_weights_reg(w, jmajor):
+    """w (cin,cout) row-major -> the register-chain kernels' chunked layout (a flat
+    tensor of cin*cout floats) through fpn_tile_weights_reg_f32."""
+    _lib.require_device_tensor("w", w, torch.float32, 2)
+    cin, cout = w.shape
+    out = torch.empty(cin * cout, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().fpn_tile_weights_reg_f32(cin, cout, int(bool(jmajor)), _lib.ptr(w), _lib.ptr(out),
+                                                        _lib.stream_of(w)))
+    return out
+
+
 def v1_seg_head(pc2d, n, table, point_feat, partial_max):
     """conv1..conv5 (+ per-128-point maxima) through fpn_v1_seg_head_f32."""
     rows, cpc = pc2d.shape
@@ -137,7 +149,8 @@ def v1_seg_head(pc2d, n, table, point_feat, partial_max):
 
 
 def v1_seg_tail(point_feat, n, gbias, table, logits):
-    """conv6..conv10 through fpn_v1_seg_tail_f32."""
+    """conv6..conv10 through fpn_v1_seg_tail_f32; gbias (frustums,512) is conv6's
+    shift with the frustum-constant part of the product folded in."""
     rows = point_feat.shape[0]
     obs = launch_observer
     tok = obs.begin("v1_seg_tail", rows, 0, 0, macs=rows * (64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2)) \

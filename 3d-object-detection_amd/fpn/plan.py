@@ -110,8 +110,17 @@ class V1Plan:
             return [ops.tile_weights(wt.contiguous()) if tiled else wt, scale, shift]
         self._head_tensors = triple("conv1", tiled=False) + \
             sum([triple(s) for s in ("conv2", "conv3", "conv4", "conv5")], [])
-        self._tail_tensors = triple("conv6", self.w6_pt) + triple("conv7") + triple("conv8") + triple("conv9") + \
+        # the tail kernel keeps activations in registers and reads its weights in
+        # 32x32 chunks (conv6, conv7 output-tile major; conv8, conv9 input-tile major);
+        # conv6's shift reaches it folded into the per-frustum term
+        def reg(scope, jmajor, w=None):
+            wt, scale, shift, _ = self.p[scope]
+            if scale is None:
+                scale = torch.ones_like(shift)
+            return [ops.tile_weights_reg((wt if w is None else w).contiguous(), jmajor), scale, shift]
+        self._tail_tensors = reg("conv6", 0, self.w6_pt)[:2] + reg("conv7", 0) + reg("conv8", 1) + reg("conv9", 1) + \
             [self.p["conv10"][0], self.p["conv10"][2]]
+        self._scale6 = self._tail_tensors[1]
         self._tnet_tensors = sum([triple(s, tiled=i > 0) for i, (s, _) in enumerate(TNET_CONV)], [])
         self._box_tensors = sum([triple(s, tiled=i > 0) for i, (s, _) in enumerate(BOX_CONV)], [])
         self._head_table = ops.pointer_table(self._head_tensors)
@@ -169,8 +178,10 @@ class V1Plan:
             partial = torch.empty((rows // hrows, 1024), dtype=torch.float32, device=dev)
             ops.v1_seg_head(x, n, self._head_table, point_feat, partial)          # conv1..conv5 :41-60
             ops.max_pool_rows(partial, n // hrows, out=gcat[:, :1024])            # maxpool :61
-            # frustum-constant part of conv6: [global_feat | one_hot] . W6[64:]
-            gbias = ops.shared_mlp(gcat, self.w6_glob, None, None, relu=False)
+            # frustum-constant part of conv6, folded into its shift:
+            # ([global_feat | one_hot] . W6[64:]) * scale6 + shift6
+            _, scale6, shift6, _ = self.p["conv6"]
+            gbias = ops.shared_mlp(gcat, self.w6_glob, scale6, shift6, relu=False)
             logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
             ops.v1_seg_tail(point_feat, n, gbias, self._tail_table, logits)       # conv6..conv10 :68-89
             del point_feat, partial

@@ -350,7 +350,10 @@ def main():
                                "share_of_step_time": secs / dt}
             out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3} for k, v in agg.items()}
         if world == 1 and not args.no_pointset:
+            # 256 frustums = one workgroup per CU for the per-frustum kernels (FPS, ball
+            # query): latency-bound; 4096 frustums lets several workgroups share a CU
             out["pointset_ops"] = pointset_ops(dev)
+            out["pointset_ops_4096_frustums"] = pointset_ops(dev, frustums=4096, reps=5)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -249,23 +249,38 @@ int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float 
                         float *point_feat, float *partial_max, void *stream);
 
 /*
+ * Weight layout of fpn_v1_seg_tail_f32, whose waves keep all activations in
+ * registers and feed the matrix cores' weight operand straight from memory:
+ * one 4 KiB chunk per (32-row input tile j, 32-column output tile t) with
+ *   chunk[(q*64 + l)*4 + i] = w[32j + 8q + 4(l/32) + i][32t + l%32]
+ * (l = lane 0..63; q, i = 0..3), chunk (t, j) stored at index t*(cin/32) + j, or,
+ * with jmajor != 0, at j*(cout/32) + t.  cin, cout multiples of 32; w_tiled has
+ * cin*cout floats and must not alias w.  No counterpart in the reference.
+ */
+int fpn_tile_weights_reg_f32(int cin, int cout, int jmajor, const float *w, float *w_tiled,
+                             void *stream);
+
+/*
  * Second half of the same net as ONE kernel: conv6..conv10
  * (models/frustum_pointnets_v1.py:68-89; dropout :84 is the identity at
  * inference).  conv6's input is [point_feat | global_feat | one_hot] (:64-66);
  * the part of the product that is the same for every point of a frustum comes in
- * as `group_bias` = [global_feat | one_hot] . W6[64:1091] (one row per frustum),
- * the kernel multiplies only point_feat by W6[0:64].  A workgroup keeps a 64-point
- * tile in LDS from conv6 to conv10; conv6's 512-wide output is produced in four
- * 128-column chunks that are consumed by conv7's accumulators at once and never
- * exist as a whole.
- *   point_feat (rows,64); group_bias (rows/n, 512); n % 64 == 0.
- *   layers: HOST array of 14 device pointers {w6[0:64],scale6,shift6, w7,scale7,
- *           shift7, w8,scale8,shift8, w9,scale9,shift9, w10, bias10} (all non-NULL);
- *           w6[0:64], w7, w8, w9 in the TILED layout of fpn_tile_weights_f32, w10
- *           row-major (128,2).
+ * folded into conv6's shift:
+ *   group_shift[f,:] = ([global_feat | one_hot][f] . W6[64:1091]) * scale6 + shift6
+ * (one row per frustum - fpn_shared_mlp_f32 with scale/shift and relu = 0 produces
+ * exactly this), the kernel multiplies only point_feat by W6[0:64].  Each wave
+ * carries 32 points from conv6 to conv10 with every activation in registers: layers
+ * are computed transposed (Y^T = W^T X^T), which leaves a layer's output in the
+ * register layout the next layer's MFMA reads its activation operand from, so
+ * nothing between point_feat and the logits touches LDS or memory.
+ *   point_feat (rows,64); group_shift (rows/n, 512); n % 32 == 0.
+ *   layers: HOST array of 13 device pointers {w6[0:64], scale6, w7, scale7, shift7,
+ *           w8, scale8, shift8, w9, scale9, shift9, w10, bias10} (all non-NULL);
+ *           w6[0:64] and w7 in fpn_tile_weights_reg_f32 layout with jmajor = 0,
+ *           w8 and w9 with jmajor = 1, w10 row-major (128,2).
  *   logits (rows,2).
  */
-int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_bias,
+int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_shift,
                         const float *const *layers, float *logits, void *stream);
 
 /*

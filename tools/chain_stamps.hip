@@ -1,6 +1,6 @@
 // Diagnostic: where does a chain-kernel workgroup spend its cycles?  Builds the chain
-// kernels with in-kernel s_memtime stamps around every barrier, runs seg_tail /
-// seg_head on random data, and prints the median cycles of each phase (compute
+// kernels with in-kernel s_memtime stamps around every barrier, runs seg_head
+// on random data, and prints the median cycles of each phase (compute
 // segment between two barriers, and the barrier wait itself) for lane 0's wave.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -I3d-object-detection_amd/csrc \
@@ -46,18 +46,6 @@ int main(int argc, char **argv)
 {
     const int frustums = argc > 1 ? atoi(argv[1]) : 256, n = 1024;
     const long rows = (long)frustums * n;
-    float *pf = dev_random(rows * 64, 1.f), *gb = dev_random((size_t)frustums * 512, 1.f);
-    float *logits;
-    hipMalloc(&logits, rows * 2 * 4);
-    const float *tail[14] = {dev_random(64 * 512, .1f),  dev_random(512, 1.f), dev_random(512, .1f),
-                             dev_random(512 * 256, .05f), dev_random(256, 1.f), dev_random(256, .1f),
-                             dev_random(256 * 128, .05f), dev_random(128, 1.f), dev_random(128, .1f),
-                             dev_random(128 * 128, .1f),  dev_random(128, 1.f), dev_random(128, .1f),
-                             dev_random(128 * 2, .1f),    dev_random(2, .1f)};
-    for (int it = 0; it < 3; ++it) fpn_v1_seg_tail_f32(rows, n, pf, gb, tail, logits, nullptr);
-    hipDeviceSynchronize();
-    report("seg_tail (8 waves, 64 rows)", rows / 64, 16, 8);   // begin + 7 barriers x 2 + end
-
     float *pc = dev_random(rows * 4, 10.f), *pfo, *part;
     hipMalloc(&pfo, rows * 64 * 4);
     hipMalloc(&part, rows / 64 * 1024 * 4);

@@ -1,0 +1,57 @@
+// Diagnostic: cycles per phase of the register-resident seg-tail kernel (median over
+// waves): prologue, conv6/conv7 loop, conv8, conv9, conv10.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -I3d-object-detection_amd/csrc -DFPN_REG_STAMPS \
+//         tools/tail_reg_stamps.hip 3d-object-detection_amd/csrc/api.cpp -x hip -o tools/bin/tail_reg_stamps
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "chain_reg.hip"
+
+static float *dev_random(size_t n, float scale)
+{
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((float)rand() / (float)RAND_MAX * 2.f - 1.f);
+    float *d;
+    if (hipMalloc(&d, n * 4) != hipSuccess) exit(1);
+    if (hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) exit(1);
+    return d;
+}
+
+int main(int argc, char **argv)
+{
+    const int frustums = argc > 1 ? atoi(argv[1]) : 128, n = 1024;
+    const long rows = (long)frustums * n;
+    float *pf = dev_random(rows * 64, 1.f), *gs = dev_random((size_t)frustums * 512, 1.f), *logits;
+    if (hipMalloc(&logits, rows * 2 * 4) != hipSuccess) return 1;
+    const float *tail[13] = {dev_random(64 * 512, .1f),   dev_random(512, 1.f),
+                             dev_random(512 * 256, .05f), dev_random(256, 1.f), dev_random(256, .1f),
+                             dev_random(256 * 128, .05f), dev_random(128, 1.f), dev_random(128, .1f),
+                             dev_random(128 * 128, .1f),  dev_random(128, 1.f), dev_random(128, .1f),
+                             dev_random(128 * 2, .1f),    dev_random(2, .1f)};
+#ifdef FPN_REG_SAMEADDR
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fpn::g_same_chunk), &tail[0], sizeof(void *)) != hipSuccess) return 5;
+#endif
+    for (int it = 0; it < 3; ++it)
+        if (fpn_v1_seg_tail_f32(rows, n, pf, gs, tail, logits, nullptr)) return 2;
+    if (hipDeviceSynchronize() != hipSuccess) return 3;
+    const long waves = rows / 32;
+    std::vector<unsigned long long> h((size_t)waves * 8);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fpn::g_reg_stamps), h.size() * 8) != hipSuccess) return 4;
+    const char *names[5] = {"prologue (weights 0,1 + point_feat)", "conv6/conv7 loop (2560 MFMA)", "conv8 (512 MFMA)",
+                            "conv9 (256 MFMA)", "conv9 epilogue + conv10"};
+    const double ideal[5] = {0, 2560 * 64.0, 512 * 64.0, 256 * 64.0, 0};
+    for (int i = 0; i < 5; ++i) {
+        std::vector<unsigned long long> d;
+        for (long w = 0; w < waves; ++w) d.push_back(h[w * 8 + i + 1] - h[w * 8 + i]);
+        std::sort(d.begin(), d.end());
+        printf("%-40s median %8llu  p10 %8llu  p90 %8llu  ideal %8.0f\n", names[i], d[d.size() / 2], d[d.size() / 10],
+               d[d.size() * 9 / 10], ideal[i]);
+    }
+    std::vector<unsigned long long> tot;
+    for (long w = 0; w < waves; ++w) tot.push_back(h[w * 8 + 5] - h[w * 8]);
+    std::sort(tot.begin(), tot.end());
+    printf("%-40s median %8llu  (ideal %d)\n", "whole wave", tot[tot.size() / 2], 3328 * 64);
+    return 0;
+}
