@@ -92,14 +92,6 @@ __device__ __forceinline__ void load_chunk(WChunk &c, const float4 *__restrict__
     for (int q = 0; q < 4; ++q) c.q[q] = p[q * 64 + lane];
 }
 
-// acc(out tile, points) += W chunk x activation tile: 16 MFMA steps
-__device__ __forceinline__ void mfma16(floatx16 &acc, const WChunk &w, const floatx16 &act)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(w.q[r >> 2], r & 3), act[r], acc, 0, 0, 0);
-}
-
 __device__ __forceinline__ void zero(floatx16 &a)
 {
 #pragma unroll
@@ -125,15 +117,18 @@ __device__ __forceinline__ void bn_relu(floatx16 &a, const TileConst &sc, const 
 }
 
 // Order of one step of NMFMA MFMAs: after each MFMA one memory read (while there are
-// any, NVMEM of them) and NVALU vector-ALU operations; nothing crosses the step's end.
-template <int NMFMA, int NVMEM, int NVALU>
+// any, NVMEM of them, in program order) and, from the VALU_FROM-th MFMA on, NVALU
+// vector-ALU operations; nothing crosses the step's end.  An epilogue that rides on a
+// step starts a few MFMAs into it (VALU_FROM = 8), so that the constants it needs -
+// requested FIRST in the step before - have had more than a step's time to arrive.
+template <int NMFMA, int NVMEM, int NVALU, int VALU_FROM = 0>
 __device__ __forceinline__ void sched_step()
 {
 #pragma unroll
     for (int m = 0; m < NMFMA; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
-        if (m < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
-        if (NVALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);    // VALU
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // MFMA
+        if (m < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // VMEM read
+        if (NVALU > 0 && m >= VALU_FROM) __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);   // VALU
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -227,8 +222,6 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
         static_for<0, 20>([&](auto I) {
             constexpr int D = decltype(I)::value;
             constexpr int cur = 2 * (D & 1), nxt = 2 * ((D + 1) & 1);
-            load_chunk(ring[nxt], tail_body_chunk<D + 1, 0>(p, kc), lane);
-            load_chunk(ring[nxt + 1], tail_body_chunk<D + 1, 1>(p, kc), lane);
             if constexpr (D == 1 || D == 3) {
                 // constants of the conv6 tile pair that this step completes; its epilogue
                 // rides on the next step
@@ -239,6 +232,12 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
                     load_const(cgs[u], gs, ch0);
                 }
             }
+            if constexpr (D == 18) {
+                load_const(c7sc, p.sc7, 4 * h);
+                load_const(c7sh, p.sh7, 4 * h);
+            }
+            load_chunk(ring[nxt], tail_body_chunk<D + 1, 0>(p, kc), lane);
+            load_chunk(ring[nxt + 1], tail_body_chunk<D + 1, 1>(p, kc), lane);
             if constexpr (D == 2 || D == 4) {   // epilogue of the pair completed by the previous step
                 bn_relu(hbuf[D - 2], csc[0], cgs[0]);
                 bn_relu(hbuf[D - 1], csc[1], cgs[1]);
@@ -255,12 +254,8 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
                 // ---- conv7 += H . W7[128 kc : 128 kc + 128, :], output pair (D-4)/4, input tile (D-4)%4
                 constexpr int m = D - 4;
                 mfma_pair(acc7[2 * (m >> 2)], acc7[2 * (m >> 2) + 1], ring[cur], ring[cur + 1], hbuf[m & 3]);
-                if constexpr (D == 18) {
-                    load_const(c7sc, p.sc7, 4 * h);
-                    load_const(c7sh, p.sh7, 4 * h);
-                }
             }
-            sched_step<32, (D == 1 || D == 3) ? 24 : (D == 18 ? 16 : 8), (D == 2 || D == 4) ? 3 : 0>();
+            sched_step<32, (D == 1 || D == 3) ? 24 : (D == 18 ? 16 : 8), (D == 2 || D == 4) ? 4 : 0, 8>();
         });
     }
 
@@ -278,18 +273,19 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
         constexpr int E = decltype(I)::value, j = E >> 1, tp = E & 1;
         constexpr int cur = 2 * (E & 1), nxt = 2 * ((E + 1) & 1);
         // the step after E = 15 is conv9's first
-        load_chunk(ring[nxt], E < 15 ? p.w8 + (size_t)(2 * E + 2) * 256 : p.w9, lane);
-        load_chunk(ring[nxt + 1], E < 15 ? p.w8 + (size_t)(2 * E + 3) * 256 : p.w9 + 256, lane);
         if constexpr (tp == 0) {
             // next input tile of conv8, or (last j) the first input tile of conv9
             load_const(ca, j < 7 ? p.sc7 : p.sc8, (j < 7 ? 32 * (j + 1) : 0) + 4 * h);
             load_const(cb, j < 7 ? p.sh7 : p.sh8, (j < 7 ? 32 * (j + 1) : 0) + 4 * h);
-        } else {
+        }
+        load_chunk(ring[nxt], E < 15 ? p.w8 + (size_t)(2 * E + 2) * 256 : p.w9, lane);
+        load_chunk(ring[nxt + 1], E < 15 ? p.w8 + (size_t)(2 * E + 3) * 256 : p.w9 + 256, lane);
+        if constexpr (tp == 1) {
             if constexpr (j < 7) bn_relu(acc7[j + 1], ca, cb);
             else bn_relu(acc8[0], ca, cb);      // complete since step (7, 0)
         }
         mfma_pair(acc8[2 * tp], acc8[2 * tp + 1], ring[cur], ring[cur + 1], acc7[j]);
-        sched_step<32, tp == 0 ? 16 : 8, tp == 0 ? 0 : 2>();
+        sched_step<32, tp == 0 ? 16 : 8, tp == 0 ? 0 : 2, 8>();
     });
     // ---- conv9: 128 -> 128 as 8 double steps, same scheme; conv8's epilogue of input tile
     //      j+1 rides on step (j, 1); in the last step the epilogue of conv9's own tile 0
@@ -300,19 +296,20 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
     static_for<0, 8>([&](auto I) {
         constexpr int F = decltype(I)::value, j = F >> 1, tp = F & 1;
         constexpr int cur = 2 * (F & 1), nxt = 2 * ((F + 1) & 1);
+        if constexpr (tp == 0) {
+            load_const(ca, j < 3 ? p.sc8 : p.sc9, (j < 3 ? 32 * (j + 1) : 0) + 4 * h);
+            load_const(cb, j < 3 ? p.sh8 : p.sh9, (j < 3 ? 32 * (j + 1) : 0) + 4 * h);
+        }
         if constexpr (F < 7) {
             load_chunk(ring[nxt], p.w9 + (size_t)(2 * F + 2) * 256, lane);
             load_chunk(ring[nxt + 1], p.w9 + (size_t)(2 * F + 3) * 256, lane);
         }
-        if constexpr (tp == 0) {
-            load_const(ca, j < 3 ? p.sc8 : p.sc9, (j < 3 ? 32 * (j + 1) : 0) + 4 * h);
-            load_const(cb, j < 3 ? p.sh8 : p.sh9, (j < 3 ? 32 * (j + 1) : 0) + 4 * h);
-        } else {
+        if constexpr (tp == 1) {
             if constexpr (j < 3) bn_relu(acc8[j + 1], ca, cb);
             else bn_relu(acc9[0], ca, cb);      // complete since step (3, 0)
         }
         mfma_pair(acc9[2 * tp], acc9[2 * tp + 1], ring[cur], ring[cur + 1], acc8[j]);
-        sched_step<32, (F < 7 ? 8 : 0) + (tp == 0 ? 8 : 0), tp == 0 ? 0 : 2>();
+        sched_step<32, (F < 7 ? 8 : 0) + (tp == 0 ? 8 : 0), tp == 0 ? 0 : 2, 8>();
     });
     // ---- rest of conv9's epilogue + conv10 (128 -> 2, plain bias) on the vector ALU
     FPN_STAMP(4);
@@ -339,6 +336,280 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
     s1 += __shfl_xor(s1, 32);
     if (h == 0) *reinterpret_cast<float2 *>(p.logits + (row0 + pt) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
     FPN_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------
+// Generic layers of a register chain.  Every layer is a run of double steps; on entry
+// ring[0], ring[1] hold the weight chunks of its first double step, on exit those of
+// the NEXT layer's first double step (next0 / next1), so that the weight stream never
+// stalls at a layer boundary.  All layers here have an even number of double steps.
+// ---------------------------------------------------------------------------
+
+// Transposed layer: out[NT] (32-channel tiles of the 32 points) = relu(bn(W^T . in[NJ])).
+// Weights: chunk (t, j) at (t*NJ + j).  The epilogue of output pair tp rides on the second
+// double step of pair tp+1; the last pair's epilogue is exposed.
+template <int NJ, int NT>
+__device__ __forceinline__ void layer_t(floatx16 (&out)[NT], const floatx16 (&in)[NJ], const float4 *__restrict__ w,
+                                        const float *__restrict__ sc, const float *__restrict__ sh, WChunk (&ring)[4],
+                                        const float4 *next0, const float4 *next1, unsigned lane, int h)
+{
+    static_assert(NJ >= 2 && NT % 2 == 0 && ((NT / 2) * NJ) % 2 == 0, "unsupported layer shape");
+    constexpr int kSteps = (NT / 2) * NJ;
+    TileConst csc[2], csh[2];
+    static_for<0, kSteps>([&](auto I) {
+        constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ;
+        constexpr int cur = 2 * (S & 1), nxt = 2 * ((S + 1) & 1);
+        constexpr bool ride_load = tp > 0 && j == 0, ride = tp > 0 && j == 1;
+        if constexpr (ride_load) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                load_const(csc[u], sc, 32 * (2 * (tp - 1) + u) + 4 * h);
+                load_const(csh[u], sh, 32 * (2 * (tp - 1) + u) + 4 * h);
+            }
+        }
+        if constexpr (S + 1 < kSteps) {
+            constexpr int tp1 = (S + 1) / NJ, j1 = (S + 1) % NJ;
+            load_chunk(ring[nxt], w + (size_t)((2 * tp1) * NJ + j1) * 256, lane);
+            load_chunk(ring[nxt + 1], w + (size_t)((2 * tp1 + 1) * NJ + j1) * 256, lane);
+        } else {
+            load_chunk(ring[nxt], next0, lane);
+            load_chunk(ring[nxt + 1], next1, lane);
+        }
+        if constexpr (ride) {
+            bn_relu(out[2 * (tp - 1)], csc[0], csh[0]);
+            bn_relu(out[2 * (tp - 1) + 1], csc[1], csh[1]);
+        }
+        if constexpr (j == 0) {
+            zero(out[2 * tp]);
+            zero(out[2 * tp + 1]);
+        }
+        mfma_pair(out[2 * tp], out[2 * tp + 1], ring[cur], ring[cur + 1], in[j]);
+        sched_step<32, ride_load ? 24 : 8, ride ? 4 : 0, 8>();
+    });
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        load_const(csc[u], sc, 32 * (NT - 2 + u) + 4 * h);
+        load_const(csh[u], sh, 32 * (NT - 2 + u) + 4 * h);
+    }
+    bn_relu(out[NT - 2], csc[0], csh[0]);
+    bn_relu(out[NT - 1], csc[1], csh[1]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The same two-tile double step with the operands swapped: the product comes out
+// UN-transposed (lane = output channel, registers = the 32 points).
+__device__ __forceinline__ void mfma_pair_n(floatx16 &acc_a, floatx16 &acc_b, const WChunk &wa, const WChunk &wb,
+                                            const floatx16 &act)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r], comp(wa.q[r >> 2], r & 3), acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(act[r], comp(wb.q[r >> 2], r & 3), acc_b, 0, 0, 0);
+    }
+}
+
+// max over the wave's 32 points of relu(acc * sc + sh) for the lane's channel, merged
+// into gmax[channel] with an integer atomic max: the values are >= +0, and for those
+// the order of the bit patterns is the order of the floats.
+__device__ __forceinline__ void max_points(const floatx16 &acc, float sc, float sh, float *gmax, int h)
+{
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r] * sc + sh);
+    // The two lane halves hold different points of the same channel.  Each issues its own
+    // update: combining them first would cost a cross-lane exchange through the LDS pipe
+    // whose wait stalls the MFMA stream, and a branch on the half would split the double
+    // step into several scheduling regions.
+    (void)h;
+    atomicMax(reinterpret_cast<int *>(gmax), __float_as_int(m));
+}
+
+// Last layer of a stack: gmax[0:32 NT] = max(gmax, max over the 32 points of
+// relu(bn(in[NJ] . W))).  Output tiles are processed four at a time (two ping-pong
+// accumulator pairs) in a rolled loop; the reduction of one pair rides on the second
+// double step of the other.  Weights: chunk (t, j) at (t*NJ + j).
+template <int NJ, int NT>
+__device__ __forceinline__ void layer_max(const floatx16 (&in)[NJ], const float4 *__restrict__ w,
+                                          const float *__restrict__ sc, const float *__restrict__ sh,
+                                          float *__restrict__ gmax, WChunk (&ring)[4], unsigned lane, int h)
+{
+    static_assert(NJ >= 2 && NJ % 2 == 0 && NT % 4 == 0, "unsupported layer shape");
+    const int c = lane & 31;
+    floatx16 acc[2][2];
+    zero(acc[1][0]);
+    zero(acc[1][1]);
+    float rsc[2], rsh[2];
+#pragma unroll 1
+    for (int t0 = 0; t0 < NT; t0 += 4) {
+        static_for<0, 2 * NJ>([&](auto I) {
+            constexpr int S = decltype(I)::value, set = S / NJ, j = S % NJ;
+            constexpr int cur = 2 * (S & 1), nxt = 2 * ((S + 1) & 1);
+            // the other accumulator pair holds the previous two tiles; the very first time
+            // there are none: constants of zero then make its reduction a no-op (max with 0)
+            // without a branch in the middle of the step
+            const bool has_prev = set == 1 || t0 > 0;
+            const int tprev = has_prev ? (set == 0 ? t0 - 2 : t0) : 0;
+            if constexpr (j == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ch = 32 * (tprev + u) + c;
+                    rsc[u] = sc[ch];      // only requested here: touching the values in this
+                    rsh[u] = sh[ch];      // step would wait for every load in flight
+                }
+                zero(acc[set][0]);
+                zero(acc[set][1]);
+            }
+            // chunks of the next double step; past the end of the layer: re-read (harmless)
+            constexpr int set1 = ((S + 1) / NJ) & 1, j1 = (S + 1) % NJ;
+            const int tn = (S + 1 < 2 * NJ ? t0 : (t0 + 4 < NT ? t0 + 4 : t0)) + 2 * set1;
+            load_chunk(ring[nxt], w + (size_t)(tn * NJ + j1) * 256, lane);
+            load_chunk(ring[nxt + 1], w + (size_t)((tn + 1) * NJ + j1) * 256, lane);
+            if constexpr (j == 1) {
+                max_points(acc[set ^ 1][0], has_prev ? rsc[0] : 0.f, has_prev ? rsh[0] : 0.f, gmax + 32 * tprev + c, h);
+                max_points(acc[set ^ 1][1], has_prev ? rsc[1] : 0.f, has_prev ? rsh[1] : 0.f,
+                           gmax + 32 * (tprev + 1) + c, h);
+            }
+            mfma_pair_n(acc[set][0], acc[set][1], ring[cur], ring[cur + 1], in[j]);
+            sched_step<32, j == 0 ? 12 : 8, j == 1 ? 5 : 0, 8>();
+        });
+    }
+    max_points(acc[1][0], sc[32 * (NT - 2) + c], sh[32 * (NT - 2) + c], gmax + 32 * (NT - 2) + c, h);
+    max_points(acc[1][1], sc[32 * (NT - 1) + c], sh[32 * (NT - 1) + c], gmax + 32 * (NT - 1) + c, h);
+}
+
+// First layer of a stack (K = 3..8 input channels straight from memory): out[NT] =
+// relu(bn(W1^T . x^T)), transposed.  x0..x3: the lane's inputs for MFMA steps 0..3, i.e.
+// channels 2s + h of its point (zero beyond the channel count); w1 (K, 32 NT) row-major.
+template <int NT, int NSTEP>
+__device__ __forceinline__ void layer_first(floatx16 (&out)[NT], const float (&x)[NSTEP], const float *__restrict__ w1,
+                                            int k_total, const float *__restrict__ sc, const float *__restrict__ sh,
+                                            unsigned lane, int h)
+{
+    const int c = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        zero(out[t]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int k = 2 * s + h;
+            const float wv = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
+            out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, x[s], out[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        TileConst csc, csh;
+        load_const(csc, sc, 32 * t + 4 * h);
+        load_const(csh, sh, 32 * t + 4 * h);
+        bn_relu(out[t], csc, csh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---------------------------------------------------------------------------
+// seg head: conv1 .. conv5 + max over points
+// ---------------------------------------------------------------------------
+struct SegHeadRegParams {
+    long rows;
+    int n, cpc;
+    const float *pc;
+    const float *w1, *sc1, *sh1;           // (cpc,64) row-major
+    const float4 *w2; const float *sc2, *sh2;   // chunked, output-tile major
+    const float4 *w3; const float *sc3, *sh3;
+    const float4 *w4; const float *sc4, *sh4;
+    const float4 *w5; const float *sc5, *sh5;
+    float *point_feat;                     // (rows,64)
+    float *gmax;                           // (rows/n, ldg): running maximum of conv5's output
+    int ldg;
+};
+
+__global__ __launch_bounds__(64 * kRegWaves) void seg_head_reg_kernel(const SegHeadRegParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+    float *gmax = p.gmax + (row0 / p.n) * p.ldg;
+    FPN_STAMP(0);
+
+    WChunk ring[4];
+    load_chunk(ring[0], p.w2, lane);                 // conv2 chunks (0,0), (1,0)
+    load_chunk(ring[1], p.w2 + 2 * 256, lane);
+
+    // conv1: lane (point, h) feeds channels h, 2+h, 4+h, 6+h of its point
+    float x[4];
+    const float *src = p.pc + (row0 + pt) * p.cpc;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
+    floatx16 a1[2], a2[2], a3[2], a4[4];
+    layer_first<2, 4>(a1, x, p.w1, p.cpc, p.sc1, p.sh1, lane, h);
+    FPN_STAMP(1);
+    layer_t<2, 2>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + 2 * 256, lane, h);
+    layer_t<2, 2>(a3, a2, p.w3, p.sc3, p.sh3, ring, p.w4, p.w4 + 2 * 256, lane, h);
+    FPN_STAMP(2);
+    // conv3's output is point_feat (models/frustum_pointnets_v1.py:49): tile t, register
+    // 4q + i = channel 32t + 8q + 4h + i
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(p.point_feat + (row0 + pt) * 64 + 32 * t + 8 * q + 4 * h) =
+                make_float4(a3[t][4 * q], a3[t][4 * q + 1], a3[t][4 * q + 2], a3[t][4 * q + 3]);
+    FPN_STAMP(3);
+    layer_t<2, 4>(a4, a3, p.w4, p.sc4, p.sh4, ring, p.w5, p.w5 + 4 * 256, lane, h);
+    FPN_STAMP(4);
+    layer_max<4, 32>(a4, p.w5, p.sc5, p.sh5, gmax, ring, lane, h);
+    FPN_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------
+// object-point stacks: T-Net 3 -> 128 -> 128 -> 256 + max, box net 3 -> 128 -> 128 ->
+// 256 -> 512 + max
+// ---------------------------------------------------------------------------
+struct ObjChainRegParams {
+    long rows;
+    int m;
+    const float *obj, *delta;
+    const float *w1, *sc1, *sh1;                // (3,128) row-major
+    const float4 *w2; const float *sc2, *sh2;
+    const float4 *w3; const float *sc3, *sh3;
+    const float4 *w4; const float *sc4, *sh4;   // box net only
+    float *gmax;                                // (rows/m, ldg)
+    int ldg;
+};
+
+template <bool BOX>
+__global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const ObjChainRegParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+    const long frustum = row0 / p.m;
+    float *gmax = p.gmax + frustum * p.ldg;
+
+    WChunk ring[4];
+    load_chunk(ring[0], p.w2, lane);                 // layer 2 chunks (0,0), (1,0)
+    load_chunk(ring[1], p.w2 + 4 * 256, lane);
+
+    // layer 1: coordinates h and 2+h of the lane's point (minus the frustum's delta)
+    float x[2];
+    const float *src = p.obj + (row0 + pt) * 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int k = 2 * s + h;
+        x[s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
+    }
+    floatx16 a1[4], a2[4];
+    layer_first<4, 2>(a1, x, p.w1, 3, p.sc1, p.sh1, lane, h);
+    layer_t<4, 4>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + 4 * 256, lane, h);
+    if constexpr (!BOX) {
+        layer_max<4, 8>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h);
+    } else {
+        floatx16 a3[8];
+        layer_t<4, 8>(a3, a2, p.w3, p.sc3, p.sh3, ring, p.w4, p.w4 + 8 * 256, lane, h);
+        layer_max<8, 16>(a3, p.w4, p.sc4, p.sh4, gmax, ring, lane, h);
+    }
 }
 
 // w (cin,cout) row-major -> 4 KiB chunks for the register chains, one per
@@ -397,6 +668,53 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
     hipLaunchKernelGGL(seg_tail_reg_kernel, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
                        as_stream(stream), p);
     return check_launch("fpn_v1_seg_tail_f32");
+}
+
+int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,
+                        float *point_feat, float *global_max, int ldg, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && n >= 1 && cpc >= 3 && cpc <= 8, "v1_seg_head: bad size rows=%ld n=%d cpc=%d", rows, n, cpc);
+    FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_head: points per frustum (%d) must be a multiple of 32", n);
+    FPN_REQUIRE(ldg >= 1024, "v1_seg_head: leading dimension of global_max (%d) must be >= 1024", ldg);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(pc && layers && point_feat && global_max, "v1_seg_head: null pointer");
+    for (int i = 0; i < 15; ++i) FPN_REQUIRE(layers[i], "v1_seg_head: layer parameter %d is null", i);
+    SegHeadRegParams p{};
+    p.rows = rows; p.n = n; p.cpc = cpc; p.pc = pc;
+    p.w1 = layers[0]; p.sc1 = layers[1]; p.sh1 = layers[2];
+    p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
+    p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
+    p.w4 = reinterpret_cast<const float4 *>(layers[9]); p.sc4 = layers[10]; p.sh4 = layers[11];
+    p.w5 = reinterpret_cast<const float4 *>(layers[12]); p.sc5 = layers[13]; p.sh5 = layers[14];
+    p.point_feat = point_feat; p.gmax = global_max; p.ldg = ldg;
+    const long waves = rows / 32;
+    hipLaunchKernelGGL(seg_head_reg_kernel, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
+                       as_stream(stream), p);
+    return check_launch("fpn_v1_seg_head_f32");
+}
+
+int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
+                         const float *const *layers, float *feat_max, int ldg, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && m >= 1, "v1_obj_chain: bad size");
+    FPN_REQUIRE(m % 32 == 0 && rows % m == 0, "v1_obj_chain: object points per frustum (%d) must be a multiple of 32", m);
+    FPN_REQUIRE(ldg >= (box ? 512 : 256), "v1_obj_chain: leading dimension of feat_max (%d) too small", ldg);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(obj && layers && feat_max, "v1_obj_chain: null pointer");
+    const int nl = box ? 12 : 9;
+    for (int i = 0; i < nl; ++i) FPN_REQUIRE(layers[i], "v1_obj_chain: layer parameter %d is null", i);
+    ObjChainRegParams p{};
+    p.rows = rows; p.m = m; p.obj = obj; p.delta = delta;
+    p.w1 = layers[0]; p.sc1 = layers[1]; p.sh1 = layers[2];
+    p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
+    p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
+    if (box) { p.w4 = reinterpret_cast<const float4 *>(layers[9]); p.sc4 = layers[10]; p.sh4 = layers[11]; }
+    p.gmax = feat_max; p.ldg = ldg;
+    const long waves = rows / 32;
+    const dim3 grid((unsigned)((waves + kRegWaves - 1) / kRegWaves));
+    if (box) hipLaunchKernelGGL(obj_chain_reg_kernel<true>, grid, dim3(64 * kRegWaves), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(obj_chain_reg_kernel<false>, grid, dim3(64 * kRegWaves), 0, as_stream(stream), p);
+    return check_launch("fpn_v1_obj_chain_f32");
 }
 
 }  // extern "C"

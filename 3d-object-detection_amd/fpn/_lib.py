@@ -45,12 +45,10 @@ SIGNATURES = {
     "fpn_shared_mlp_flipout_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
                                    _vp, _i, _vp, _sz, _vp],
     "fpn_max_pool_rows": [_l, _i, _i, _vp, _i, _vp, _i, _vp],
-    "fpn_tile_weights_f32": [_i, _i, _vp, _vp, _vp],
     "fpn_tile_weights_reg_f32": [_i, _i, _i, _vp, _vp, _vp],
-    "fpn_v1_chain_rows": [_i],
-    "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
-    "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_box3d_iou_f64": [_l, _vp, _l, _vp, _l, _vp, _vp],
     "fpn_box3d_best_overlap_f64": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

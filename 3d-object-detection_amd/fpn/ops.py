@@ -106,23 +106,6 @@ def pointer_table(tensors):
     return arr
 
 
-def chain_rows(which):
-    """Rows per workgroup of the chain kernels (0: seg head, 1: object chains): the
-    granularity of their partial_max outputs."""
-    return _lib.load().fpn_v1_chain_rows(which)
-
-
-def tile_weights(w):
-    """w (cin,cout) row-major -> the chain kernels' tiled layout (a flat tensor of
-    cin*cout floats) through fpn_tile_weights_f32."""
-    _lib.require_device_tensor("w", w, torch.float32, 2)
-    cin, cout = w.shape
-    out = torch.empty(cin * cout, dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
-        _lib.check(_lib.load().fpn_tile_weights_f32(cin, cout, _lib.ptr(w), _lib.ptr(out), _lib.stream_of(w)))
-    return out
-
-
 def tile_weights_reg(w, jmajor):
     """w (cin,cout) row-major -> the register-chain kernels' chunked layout (a flat
     tensor of cin*cout floats) through fpn_tile_weights_reg_f32."""
@@ -135,15 +118,21 @@ def tile_weights_reg(w, jmajor):
     return out
 
 
-def v1_seg_head(pc2d, n, table, point_feat, partial_max):
-    """conv1..conv5 (+ per-128-point maxima) through fpn_v1_seg_head_f32."""
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def v1_seg_head(pc2d, n, table, point_feat, global_max):
+    """conv1..conv5 + max over each frustum's points through fpn_v1_seg_head_f32;
+    global_max (frustums, >=1024) must hold zeros (or a running maximum) in its first
+    1024 columns and may be a view into a wider buffer."""
     rows, cpc = pc2d.shape
     obs = launch_observer
     tok = obs.begin("v1_seg_head", rows, 0, 0, macs=rows * (cpc * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024)) \
         if obs is not None else None
     with torch.cuda.device(pc2d.device):
         _lib.check(_lib.load().fpn_v1_seg_head_f32(rows, int(n), cpc, _lib.ptr(pc2d), table, _lib.ptr(point_feat),
-                                                   _lib.ptr(partial_max), _lib.stream_of(pc2d)))
+                                                   _lib.ptr(global_max), _ld(global_max), _lib.stream_of(pc2d)))
     if obs is not None:
         obs.end(tok)
 
@@ -162,9 +151,10 @@ def v1_seg_tail(point_feat, n, gbias, table, logits):
         obs.end(tok)
 
 
-def v1_obj_chain(obj2d, m, box, delta, table, partial_max):
-    """T-Net (box=False) or box-net (box=True) convolution stack through
-    fpn_v1_obj_chain_f32; `delta` (frustums,3) or None."""
+def v1_obj_chain(obj2d, m, box, delta, table, feat_max):
+    """T-Net (box=False) or box-net (box=True) convolution stack + max over the object
+    points through fpn_v1_obj_chain_f32; `delta` (frustums,3) or None; feat_max
+    (frustums, >=256 / >=512) zeroed (or a running maximum), possibly a view."""
     rows = obj2d.shape[0]
     macs = 3 * 128 + 128 * 128 + 128 * 256 + (256 * 512 if box else 0)
     obs = launch_observer
@@ -172,7 +162,8 @@ def v1_obj_chain(obj2d, m, box, delta, table, partial_max):
         if obs is not None else None
     with torch.cuda.device(obj2d.device):
         _lib.check(_lib.load().fpn_v1_obj_chain_f32(rows, int(m), int(bool(box)), _lib.ptr(obj2d), _lib.ptr(delta),
-                                                    table, _lib.ptr(partial_max), _lib.stream_of(obj2d)))
+                                                    table, _lib.ptr(feat_max), _ld(feat_max),
+                                                    _lib.stream_of(obj2d)))
     if obs is not None:
         obs.end(tok)
 

@@ -100,29 +100,21 @@ class V1Plan:
             self._version = st.version
             return
 
-        def triple(scope, w=None, tiled=True):
+        # The chain kernels keep activations in registers and read their weights in 32x32
+        # chunks (fpn_tile_weights_reg_f32; conv8 and conv9 input-tile major, all others
+        # output-tile major); the first layer of each stack (K = 3 or 4) takes plain w.
+        def reg(scope, jmajor=0, w=None, tiled=True):
             wt, scale, shift, _ = self.p[scope]
             if scale is None:
                 scale = torch.ones_like(shift)
-            wt = wt if w is None else w
-            # matrix-core layers read their weights in the tiled layout; the first
-            # layer of each stack (K = 3 or 4) runs on the vector ALU from plain w
-            return [ops.tile_weights(wt.contiguous()) if tiled else wt, scale, shift]
-        self._head_tensors = triple("conv1", tiled=False) + \
-            sum([triple(s) for s in ("conv2", "conv3", "conv4", "conv5")], [])
-        # the tail kernel keeps activations in registers and reads its weights in
-        # 32x32 chunks (conv6, conv7 output-tile major; conv8, conv9 input-tile major);
-        # conv6's shift reaches it folded into the per-frustum term
-        def reg(scope, jmajor, w=None):
-            wt, scale, shift, _ = self.p[scope]
-            if scale is None:
-                scale = torch.ones_like(shift)
-            return [ops.tile_weights_reg((wt if w is None else w).contiguous(), jmajor), scale, shift]
+            wt = (wt if w is None else w).contiguous()
+            return [ops.tile_weights_reg(wt, jmajor) if tiled else wt, scale, shift]
+        self._head_tensors = reg("conv1", tiled=False) + sum([reg(s) for s in ("conv2", "conv3", "conv4", "conv5")], [])
+        self._tnet_tensors = sum([reg(s, tiled=i > 0) for i, (s, _) in enumerate(TNET_CONV)], [])
+        self._box_tensors = sum([reg(s, tiled=i > 0) for i, (s, _) in enumerate(BOX_CONV)], [])
+        # conv6's shift reaches the tail kernel folded into the per-frustum term
         self._tail_tensors = reg("conv6", 0, self.w6_pt)[:2] + reg("conv7", 0) + reg("conv8", 1) + reg("conv9", 1) + \
             [self.p["conv10"][0], self.p["conv10"][2]]
-        self._scale6 = self._tail_tensors[1]
-        self._tnet_tensors = sum([triple(s, tiled=i > 0) for i, (s, _) in enumerate(TNET_CONV)], [])
-        self._box_tensors = sum([triple(s, tiled=i > 0) for i, (s, _) in enumerate(BOX_CONV)], [])
         self._head_table = ops.pointer_table(self._head_tensors)
         self._tail_table = ops.pointer_table(self._tail_tensors)
         self._tnet_table = ops.pointer_table(self._tnet_tensors)
@@ -138,8 +130,8 @@ class V1Plan:
         # conv7's 256: ~3.6 KB per point with the smaller buffers; a chunk of 1 GiB
         # keeps the launch count low (the layers are compute-bound, so spilling the
         # Infinity Cache costs little) while bounding the transient footprint
-        if self.chain and n % 128 == 0:
-            # the chain kernels keep activations in LDS: per point only point_feat
+        if self.chain:
+            # the chain kernels keep activations in registers: per point only point_feat
             # (256 B), the logits and the mask reach memory
             return max(1, min(4096, (1 << 30) // (n * 320)))
         per_frustum = n * 3700
@@ -172,19 +164,17 @@ class V1Plan:
         # --- instance segmentation net (frustum_pointnets_v1.py:20-90) -------------
         gcat = torch.empty((b, 1024 + 3), dtype=torch.float32, device=dev)
         gcat[:, 1024:] = one_hot                                        # concat one-hot :64
-        if self.chain and n % 128 == 0:
+        if self.chain:
             point_feat = torch.empty((rows, 64), dtype=torch.float32, device=dev)
-            hrows = ops.chain_rows(0)     # points per workgroup of the head kernel
-            partial = torch.empty((rows // hrows, 1024), dtype=torch.float32, device=dev)
-            ops.v1_seg_head(x, n, self._head_table, point_feat, partial)          # conv1..conv5 :41-60
-            ops.max_pool_rows(partial, n // hrows, out=gcat[:, :1024])            # maxpool :61
+            gcat[:, :1024] = 0                    # the head kernel accumulates the maximum in place
+            ops.v1_seg_head(x, n, self._head_table, point_feat, gcat)      # conv1..conv5 + maxpool :41-61
             # frustum-constant part of conv6, folded into its shift:
             # ([global_feat | one_hot] . W6[64:]) * scale6 + shift6
             _, scale6, shift6, _ = self.p["conv6"]
             gbias = ops.shared_mlp(gcat, self.w6_glob, scale6, shift6, relu=False)
             logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
             ops.v1_seg_tail(point_feat, n, gbias, self._tail_table, logits)       # conv6..conv10 :68-89
-            del point_feat, partial
+            del point_feat
         else:
             a = self._layer(x, "conv1")
             a = self._layer(a, "conv2")
@@ -211,11 +201,8 @@ class V1Plan:
         tcat[:, 256:] = one_hot
         obj2d = obj.reshape(b * m, 3)
         if self.chain:
-            orows = ops.chain_rows(1)     # object points per workgroup of the chain kernels
-            opart = torch.empty((b * m // orows, 512), dtype=torch.float32, device=dev)
-            tpart = opart.view(-1)[:b * m // orows * 256].view(b * m // orows, 256)
-            ops.v1_obj_chain(obj2d, m, False, None, self._tnet_table, tpart)
-            ops.max_pool_rows(tpart, m // orows, out=tcat[:, :256])
+            tcat[:, :256] = 0
+            ops.v1_obj_chain(obj2d, m, False, None, self._tnet_table, tcat)     # conv stack + maxpool :335-347
         else:
             t = self._layer(obj2d, "conv-reg1-stage1")
             t = self._layer(t, "conv-reg2-stage1")
@@ -230,8 +217,8 @@ class V1Plan:
         bcat[:, 512:] = one_hot
         if self.chain:
             # the kernel subtracts center_delta while loading the tile (:176-177)
-            ops.v1_obj_chain(obj2d, m, True, center_delta, self._box_table, opart)
-            ops.max_pool_rows(opart, m // orows, out=bcat[:, :512])
+            bcat[:, :512] = 0
+            ops.v1_obj_chain(obj2d, m, True, center_delta, self._box_table, bcat)   # :108-124
         else:
             obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)     # :176-177
             t = self._layer(obj_new, "conv-reg1")

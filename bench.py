@@ -98,8 +98,8 @@ def cpu_baseline(seconds=12.0):
 PEAK_HBM_GBS = 8000.0   # MI355X HBM3E spec peak, GB/s
 
 # observer name of a launch -> kernel name in the rocprofv3 counter summaries
-PMC_KERNEL = {"v1_seg_tail": "seg_tail_kernel", "v1_seg_head": "seg_head_kernel",
-              "v1_obj_chain_box": "obj_chain_kernel<true>", "v1_obj_chain_tnet": "obj_chain_kernel<false>"}
+PMC_KERNEL = {"v1_seg_tail": "seg_tail_reg_kernel", "v1_seg_head": "seg_head_reg_kernel",
+              "v1_obj_chain_box": "obj_chain_reg_kernel<true>", "v1_obj_chain_tnet": "obj_chain_reg_kernel<false>"}
 
 
 def measured_traffic(name, batch, points):

@@ -207,23 +207,6 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
                                int relu, int pool_rows, float *y, int ldy, void *workspace,
                                size_t workspace_bytes, void *stream);
 
-/*
- * Weight layout of the layer-chain kernels below.  They feed the matrix cores
- * straight from global memory, one 16-byte load per lane; this re-orders a
- * row-major w (cin,cout) so that those loads are contiguous across a wavefront:
- *   w_tiled[(((ct*(cin/32) + kb)*4 + q)*64 + l)*4 + j]
- *       = w[kb*32 + 16*(l/32) + 4*q + j][ct*32 + l%32]
- * (ct = 32-column tile, kb = 32-row block, l = lane 0..63, q,j = 0..3).  Done once
- * per weight matrix when a checkpoint is loaded; w_tiled has cin*cout floats and
- * must not alias w.  cin % 64 == 0, cout % 32 == 0.  No counterpart in the
- * reference (TensorFlow owns its conv kernels' layouts, models/tf_util.py:142-170).
- */
-int fpn_tile_weights_f32(int cin, int cout, const float *w, float *w_tiled, void *stream);
-
-/* Points per workgroup of fpn_v1_seg_head_f32 (which = 0) or fpn_v1_obj_chain_f32
- * (which = 1): the row granularity of their partial_max outputs. */
-int fpn_v1_chain_rows(int which);
-
 /* Largest squared distance s for which the reference's ball test
  * max(sqrtf(s), 1e-20f) < radius holds (models/tf_ops/grouping/tf_grouping_g.cu:24),
  * or -1 when no distance passes, so that fpn_query_ball_point can compare squared distances and still accept
@@ -233,24 +216,30 @@ float fpn_ball_threshold(float radius);
 /*
  * First half of the v1 instance-segmentation net as ONE kernel: conv1..conv5 of
  * get_instance_seg_v1_net (models/frustum_pointnets_v1.py:41-60) with their
- * bias/batch-norm/ReLU, plus the per-128-point part of the max-pool at :61.
- * A workgroup keeps a 128-point tile in LDS through all five layers; only the
- * point cloud is read and only conv3's output (`point_feat`, :49, needed again by
- * conv6) and the column maxima are written.
- *   pc (rows, cpc) with 3 <= cpc <= 8;  rows = frustums * n, n % 128 == 0.
+ * bias/batch-norm/ReLU, and the max-pool over the frustum's points at :61.
+ * Each wave carries 32 points through all five layers with the activations in
+ * registers (see fpn_v1_seg_tail_f32); only the point cloud is read and only
+ * conv3's output (`point_feat`, :49, needed again by conv6) and the maxima are
+ * written.  The maximum over a frustum's points is accumulated with atomic max
+ * operations (ReLU output is >= 0, so integer atomics on the bit patterns order
+ * correctly and the result does not depend on the order of arrival).
+ *   pc (rows, cpc) with 3 <= cpc <= 8;  rows = frustums * n, n % 32 == 0.
  *   layers: HOST array of 15 device pointers {w,scale,shift} x {conv1..conv5};
- *           conv1's w row-major (cpc,64), the other four in the TILED layout of
- *           fpn_tile_weights_f32; scale/shift as in fpn_shared_mlp_f32 (all non-NULL).
- *   point_feat (rows,64); partial_max (rows/R, 1024) with R = fpn_v1_chain_rows(0)
- *   (128): the maximum of conv5's output over each workgroup's R points; finish with
- *   fpn_max_pool_rows(rows/R, 1024, n/R, partial_max, 1024, global_feat, ld).
+ *           conv1's w row-major (cpc,64), the other four in
+ *           fpn_tile_weights_reg_f32 layout with jmajor = 0; scale/shift as in
+ *           fpn_shared_mlp_f32 (all non-NULL).
+ *   point_feat (rows,64).
+ *   global_max (rows/n, ldg), ldg >= 1024: columns 0..1023 of row f receive
+ *           max(previous content, max over the points of frustum f of conv5's
+ *           output) - the caller ZEROES those columns before the call (or passes a
+ *           running maximum, e.g. when a frustum's points arrive in several calls).
  */
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,
-                        float *point_feat, float *partial_max, void *stream);
+                        float *point_feat, float *global_max, int ldg, void *stream);
 
 /*
- * Weight layout of fpn_v1_seg_tail_f32, whose waves keep all activations in
- * registers and feed the matrix cores' weight operand straight from memory:
+ * Weight layout of the fpn_v1_* chain kernels, whose waves keep all activations
+ * in registers and feed the matrix cores' weight operand straight from memory:
  * one 4 KiB chunk per (32-row input tile j, 32-column output tile t) with
  *   chunk[(q*64 + l)*4 + i] = w[32j + 8q + 4(l/32) + i][32t + l%32]
  * (l = lane 0..63; q, i = 0..3), chunk (t, j) stored at index t*(cin/32) + j, or,
@@ -284,26 +273,26 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
                         const float *const *layers, float *logits, void *stream);
 
 /*
- * Convolution stack over the object points as ONE kernel, 64 points per
- * workgroup, activations resident in LDS:
+ * Convolution stack over the object points as ONE kernel, 32 points per wave,
+ * activations in registers:
  *   box == 0: T-Net, conv-reg1-stage1..conv-reg3-stage1 (3->128->128->256) of
- *             get_center_regression_net (models/model_util.py:335-346) and the
- *             per-64-point part of its max-pool (:347);
+ *             get_center_regression_net (models/model_util.py:335-346) and its
+ *             max-pool over the object points (:347);
  *   box != 0: box net, conv-reg1..conv-reg4 (3->128->128->256->512) of
  *             get_3d_box_estimation_v1_net (models/frustum_pointnets_v1.py:108-123)
- *             and the per-64-point part of its max-pool (:124).
+ *             and its max-pool (:124).
  * `delta` (rows/m, 3), if not NULL, is subtracted from every point of the frustum
- * as the tile is loaded: the translation to the T-Net's centre estimate of
+ * as it is loaded: the translation to the T-Net's centre estimate of
  * frustum_pointnets_v1.py:176-177.
- *   obj (rows,3), rows = frustums * m, m % 64 == 0.
+ *   obj (rows,3), rows = frustums * m, m % 32 == 0.
  *   layers: HOST array of 9 (T-Net) or 12 (box) device pointers {w,scale,shift};
- *           the first layer's w row-major (3,128), the others in the TILED layout
- *           of fpn_tile_weights_f32.
- *   partial_max (rows/R, 256 or 512) with R = fpn_v1_chain_rows(1) (64); finish
- *   with fpn_max_pool_rows over m/R rows.
+ *           the first layer's w row-major (3,128), the others in
+ *           fpn_tile_weights_reg_f32 layout with jmajor = 0.
+ *   feat_max (rows/m, ldg), ldg >= 256 (T-Net) or 512 (box): running maximum as in
+ *           fpn_v1_seg_head_f32 - the caller zeroes columns 0..255 / 0..511 first.
  */
 int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
-                         const float *const *layers, float *partial_max, void *stream);
+                         const float *const *layers, float *feat_max, int ldg, void *stream);
 
 /*
  * Mask, masked centroid and object-point gather of point_cloud_masking +

@@ -146,14 +146,17 @@ def test_v1_oracle_fp64_error_budget(device):
 
 
 def test_chain_kernels_match_layer_path(device):
-    """The layer-chain segmentation kernels against the one-layer-per-launch path
-    (same weights, same inputs): logits within the fp32 summation-order band."""
+    """The register-chain kernels against the one-layer-per-launch path (same weights,
+    same inputs): logits within the fp32 summation-order band.  96 and 160 points per
+    frustum give wave counts that are not a multiple of the workgroup's four waves
+    (surplus waves leave early) and frustum boundaries inside a workgroup."""
     from fpn import plan, synthetic
     st = make_store(device, seed=11)
-    for n in (1024, 2048, 128):
-        pc, one_hot = synthetic.make_frustums(5, n, 4, seed=n)
+    for b_, n in ((5, 1024), (5, 2048), (5, 128), (3, 96), (5, 160), (1, 32)):
+        pc, one_hot = synthetic.make_frustums(b_, n, 4, seed=n)
         a = plan.V1Plan(st, 4, True, chain=True).forward(dev(pc, device), dev(one_hot, device))
-        b = plan.V1Plan(st, 4, True, chain=False).forward(dev(pc, device), dev(one_hot, device))
-        close(a["mask_logits"].cpu().numpy(), b["mask_logits"].cpu().numpy(), 1e-4)
+        if n % 128 == 0 or n in (32, 64):     # group sizes the per-layer kernel can max-pool in its epilogue
+            b = plan.V1Plan(st, 4, True, chain=False).forward(dev(pc, device), dev(one_hot, device))
+            close(a["mask_logits"].cpu().numpy(), b["mask_logits"].cpu().numpy(), 1e-4)
         want = V.get_model(pc, one_hot, st.numpy())
         compare_end_points(a, want, pc, one_hot, st.numpy())

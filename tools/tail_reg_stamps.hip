@@ -53,5 +53,29 @@ int main(int argc, char **argv)
     for (long w = 0; w < waves; ++w) tot.push_back(h[w * 8 + 5] - h[w * 8]);
     std::sort(tot.begin(), tot.end());
     printf("%-40s median %8llu  (ideal %d)\n", "whole wave", tot[tot.size() / 2], 3328 * 64);
+
+    // ---- seg head
+    float *pc = dev_random(rows * 4, 10.f), *pfo, *gmax;
+    if (hipMalloc(&pfo, rows * 64 * 4) != hipSuccess || hipMalloc(&gmax, (size_t)frustums * 1024 * 4) != hipSuccess) return 1;
+    if (hipMemset(gmax, 0, (size_t)frustums * 1024 * 4) != hipSuccess) return 1;
+    const float *head[15] = {dev_random(4 * 64, .3f),     dev_random(64, 1.f),   dev_random(64, .1f),
+                             dev_random(64 * 64, .1f),    dev_random(64, 1.f),   dev_random(64, .1f),
+                             dev_random(64 * 64, .1f),    dev_random(64, 1.f),   dev_random(64, .1f),
+                             dev_random(64 * 128, .1f),   dev_random(128, 1.f),  dev_random(128, .1f),
+                             dev_random(128 * 1024, .1f), dev_random(1024, 1.f), dev_random(1024, .1f)};
+    for (int it = 0; it < 3; ++it)
+        if (fpn_v1_seg_head_f32(rows, n, 4, pc, head, pfo, gmax, 1024, nullptr)) return 2;
+    if (hipDeviceSynchronize() != hipSuccess) return 3;
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fpn::g_reg_stamps), h.size() * 8) != hipSuccess) return 4;
+    const char *hn[5] = {"conv1 (operands from memory)", "conv2 + conv3 (128 MFMA)", "point_feat store",
+                         "conv4 (128 MFMA)", "conv5 + max (2048 MFMA)"};
+    const double hi[5] = {0, 128 * 64.0, 0, 128 * 64.0, 2048 * 64.0};
+    for (int i = 0; i < 5; ++i) {
+        std::vector<unsigned long long> d;
+        for (long w = 0; w < waves; ++w) d.push_back(h[w * 8 + i + 1] - h[w * 8 + i]);
+        std::sort(d.begin(), d.end());
+        printf("%-40s median %8llu  p10 %8llu  p90 %8llu  ideal %8.0f\n", hn[i], d[d.size() / 2], d[d.size() / 10],
+               d[d.size() * 9 / 10], hi[i]);
+    }
     return 0;
 }
