@@ -18,6 +18,8 @@
 namespace fpn {
 namespace {
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float sqdist3(float x2, float y2, float z2, float x1, float y1, float z1)
 {
     float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
@@ -78,15 +80,23 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float 
     for (int i = tid; i < n * 3; i += THREADS) sxyz[i] = pts[i];
     __syncthreads();
 
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    // The thread's points are kept as PAIRS: the subtract / multiply / add chain of the
+    // squared distance then runs on the packed fp32 instructions (v_pk_add_f32,
+    // v_pk_mul_f32: two IEEE-rounded results per instruction, same values as the scalar
+    // forms), which is what bounds this kernel once several frustums share a CU.
+    constexpr int NP = (PPT + 1) / 2;   // with an odd PPT the last pair's second half is unused
+    float2v px[NP], py[NP], pz[NP];
+#pragma unroll
+    for (int s2 = 0; s2 < NP; ++s2) px[s2] = py[s2] = pz[s2] = float2v{0.f, 0.f};
+    float md[PPT];
     const int base = tid * PPT;
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         int k = base + s;
         bool valid = k < n;
-        px[s] = valid ? sxyz[k * 3 + 0] : 0.f;
-        py[s] = valid ? sxyz[k * 3 + 1] : 0.f;
-        pz[s] = valid ? sxyz[k * 3 + 2] : 0.f;
+        px[s >> 1][s & 1] = valid ? sxyz[k * 3 + 0] : 0.f;
+        py[s >> 1][s & 1] = valid ? sxyz[k * 3 + 1] : 0.f;
+        pz[s >> 1][s & 1] = valid ? sxyz[k * 3 + 2] : 0.f;
         // slots past the end start at distance 0 with an index above every real
         // point: they can tie only when every real point is at 0 too, and then
         // point 0 (lower index) wins.
@@ -100,13 +110,20 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float 
         float best = -1.f;
         int besti = 0;
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            float d = sqdist3(px[s], py[s], pz[s], x1, y1, z1);
-            float d2 = d < md[s] ? d : md[s];
-            md[s] = d2;
-            if (d2 > best) {
-                best = d2;
-                besti = base + s;
+        for (int s2 = 0; s2 < NP; ++s2) {
+            // (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1), left to right, for two points
+            const float2v dx = px[s2] - x1, dy = py[s2] - y1, dz = pz[s2] - z1;
+            float2v d = dx * dx + dy * dy;
+            d = d + dz * dz;
+#pragma unroll
+            for (int e = 0; e < 2 && 2 * s2 + e < PPT; ++e) {
+                const int s = 2 * s2 + e;
+                float d2 = d[e] < md[s] ? d[e] : md[s];
+                md[s] = d2;
+                if (d2 > best) {
+                    best = d2;
+                    besti = base + s;
+                }
             }
         }
         const unsigned key = __float_as_uint(best);
