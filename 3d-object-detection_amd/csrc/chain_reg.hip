@@ -342,23 +342,24 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
 // Generic layers of a register chain.  Every layer is a run of double steps; on entry
 // ring[0], ring[1] hold the weight chunks of its first double step, on exit those of
 // the NEXT layer's first double step (next0 / next1), so that the weight stream never
-// stalls at a layer boundary.  All layers here have an even number of double steps.
+// stalls at a layer boundary.  A layer whose number of double steps is odd hands the
+// stream over in ring[2], ring[3]: P0 is the ring half (0 or 1) a layer starts in.
 // ---------------------------------------------------------------------------
 
 // Transposed layer: out[NT] (32-channel tiles of the 32 points) = relu(bn(W^T . in[NJ])).
 // Weights: chunk (t, j) at (t*NJ + j).  The epilogue of output pair tp rides on the second
 // double step of pair tp+1; the last pair's epilogue is exposed.
-template <int NJ, int NT>
+template <int NJ, int NT, int P0 = 0>
 __device__ __forceinline__ void layer_t(floatx16 (&out)[NT], const floatx16 (&in)[NJ], const float4 *__restrict__ w,
                                         const float *__restrict__ sc, const float *__restrict__ sh, WChunk (&ring)[4],
                                         const float4 *next0, const float4 *next1, unsigned lane, int h)
 {
-    static_assert(NJ >= 2 && NT % 2 == 0 && ((NT / 2) * NJ) % 2 == 0, "unsupported layer shape");
+    static_assert(NJ >= 2 && NT % 2 == 0, "unsupported layer shape");
     constexpr int kSteps = (NT / 2) * NJ;
     TileConst csc[2], csh[2];
     static_for<0, kSteps>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ;
-        constexpr int cur = 2 * (S & 1), nxt = 2 * ((S + 1) & 1);
+        constexpr int cur = 2 * ((S + P0) & 1), nxt = 2 * ((S + P0 + 1) & 1);
         constexpr bool ride_load = tp > 0 && j == 0, ride = tp > 0 && j == 1;
         if constexpr (ride_load) {
 #pragma unroll
@@ -428,10 +429,12 @@ __device__ __forceinline__ void max_points(const floatx16 &acc, float sc, float 
 // relu(bn(in[NJ] . W))).  Output tiles are processed four at a time (two ping-pong
 // accumulator pairs) in a rolled loop; the reduction of one pair rides on the second
 // double step of the other.  Weights: chunk (t, j) at (t*NJ + j).
-template <int NJ, int NT>
+// Channels >= cvalid (output widths padded up to a multiple of 128) are not written.
+template <int NJ, int NT, int P0 = 0>
 __device__ __forceinline__ void layer_max(const floatx16 (&in)[NJ], const float4 *__restrict__ w,
                                           const float *__restrict__ sc, const float *__restrict__ sh,
-                                          float *__restrict__ gmax, WChunk (&ring)[4], unsigned lane, int h)
+                                          float *__restrict__ gmax, WChunk (&ring)[4], unsigned lane, int h,
+                                          int cvalid = 32 * NT)
 {
     static_assert(NJ >= 2 && NJ % 2 == 0 && NT % 4 == 0, "unsupported layer shape");
     const int c = lane & 31;
@@ -443,12 +446,13 @@ __device__ __forceinline__ void layer_max(const floatx16 (&in)[NJ], const float4
     for (int t0 = 0; t0 < NT; t0 += 4) {
         static_for<0, 2 * NJ>([&](auto I) {
             constexpr int S = decltype(I)::value, set = S / NJ, j = S % NJ;
-            constexpr int cur = 2 * (S & 1), nxt = 2 * ((S + 1) & 1);
+            constexpr int cur = 2 * ((S + P0) & 1), nxt = 2 * ((S + P0 + 1) & 1);
             // the other accumulator pair holds the previous two tiles; the very first time
-            // there are none: constants of zero then make its reduction a no-op (max with 0)
-            // without a branch in the middle of the step
-            const bool has_prev = set == 1 || t0 > 0;
-            const int tprev = has_prev ? (set == 0 ? t0 - 2 : t0) : 0;
+            // there are none (and padded tiles are never wanted): constants of zero then make
+            // the reduction a no-op (max with 0) without a branch in the middle of the step
+            const int tcand = set == 0 ? t0 - 2 : t0;
+            const bool has_prev = (set == 1 || t0 > 0) && 32 * tcand < cvalid;
+            const int tprev = has_prev ? tcand : 0;
             if constexpr (j == 0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -473,8 +477,10 @@ __device__ __forceinline__ void layer_max(const floatx16 (&in)[NJ], const float4
             sched_step<32, j == 0 ? 12 : 8, j == 1 ? 5 : 0, 8>();
         });
     }
-    max_points(acc[1][0], sc[32 * (NT - 2) + c], sh[32 * (NT - 2) + c], gmax + 32 * (NT - 2) + c, h);
-    max_points(acc[1][1], sc[32 * (NT - 1) + c], sh[32 * (NT - 1) + c], gmax + 32 * (NT - 1) + c, h);
+    if (32 * (NT - 2) < cvalid) {
+        max_points(acc[1][0], sc[32 * (NT - 2) + c], sh[32 * (NT - 2) + c], gmax + 32 * (NT - 2) + c, h);
+        max_points(acc[1][1], sc[32 * (NT - 1) + c], sh[32 * (NT - 1) + c], gmax + 32 * (NT - 1) + c, h);
+    }
 }
 
 // First layer of a stack (K = 3..8 input channels straight from memory): out[NT] =
@@ -612,6 +618,93 @@ __global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const Obj
     }
 }
 
+// ---------------------------------------------------------------------------
+// Set-abstraction module (models/pointnet_util.py:86-195) as one kernel: grouping
+// (gather of the ball's points, translation to the centroid, concatenation with the
+// point features), the three shared-MLP layers and the max over the ball's samples.
+// A wave takes 32 consecutive samples of one ball; the grouped tensor never exists.
+//   NJF > 0: the point features (32 NJF channels) are gathered as activation tiles and
+//            the 3 relative coordinates ride in one more tile (its other 29 channels are
+//            zero, as are the matching rows of the caller's padded first-layer weights);
+//   NJF = 0: at most 8 input channels [dx,dy,dz, features...]: first layer from memory.
+// Layer widths are 32 NT1, 32 NT2, 32 NT3 (the caller pads narrower layers with zero
+// weights / scale / shift); columns >= c3 of the last layer are not written.
+// ---------------------------------------------------------------------------
+struct SaChainParams {
+    long rows;            // b * m * ns grouped rows
+    int n, m, ns, cf;     // dataset points, balls per frustum, samples per ball, feature channels
+    const float *xyz;     // (b,n,3)
+    const float *new_xyz; // (b,m,3)
+    const float *feat;    // (b,n,cf) or NULL
+    const int *idx;       // (b,m,ns)
+    const float *w1; const float *sc1, *sh1;     // NJF > 0: chunked ((NJF+1)*32, 32 NT1); NJF = 0: plain (3+cf, 32 NT1)
+    const float4 *w2; const float *sc2, *sh2;
+    const float4 *w3; const float *sc3, *sh3;
+    float *out;           // (b*m, ldo): running maximum, columns [0, c3) of the caller's slice
+    int ldo, c3;
+};
+
+template <int NJF, int NT1, int NT2, int NT3>
+__global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+    const long ball = row0 / p.ns;                    // = b * m + j
+    const long b = ball / p.m;
+    const int pid = p.idx[row0 + pt];                 // this lane's neighbour
+    const float *ctr = p.new_xyz + ball * 3;
+    const float *src = p.xyz + (b * p.n + pid) * 3;
+    float *gmax = p.out + ball * p.ldo;
+
+    WChunk ring[4];
+    constexpr int NJ1 = NJF > 0 ? NJF + 1 : 2;       // input tiles of layer 1 (unused when NJF = 0)
+    floatx16 a1[NT1], a2[NT2];
+    if constexpr (NJF > 0) {
+        const float4 *w1c = reinterpret_cast<const float4 *>(p.w1);
+        load_chunk(ring[0], w1c, lane);
+        load_chunk(ring[1], w1c + (size_t)NJ1 * 256, lane);
+        floatx16 in[NJ1];
+        const float *f = p.feat + (b * p.n + pid) * (long)p.cf;
+#pragma unroll
+        for (int t = 0; t < NJF; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(f + 32 * t + 8 * q + 4 * h);
+                in[t][4 * q + 0] = v.x; in[t][4 * q + 1] = v.y; in[t][4 * q + 2] = v.z; in[t][4 * q + 3] = v.w;
+            }
+        zero(in[NJF]);
+        // channels 0..2 of the last tile live in registers 0..2 of the lower lane half
+        in[NJF][0] = h == 0 ? src[0] - ctr[0] : 0.f;
+        in[NJF][1] = h == 0 ? src[1] - ctr[1] : 0.f;
+        in[NJF][2] = h == 0 ? src[2] - ctr[2] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        layer_t<NJ1, NT1, 0>(a1, in, w1c, p.sc1, p.sh1, ring, p.w2, p.w2 + (size_t)NT1 * 256, lane, h);
+        constexpr int P1 = ((NT1 / 2) * NJ1) & 1;
+        layer_t<NT1, NT2, P1>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
+        constexpr int P2 = (P1 + (NT2 / 2) * NT1) & 1;
+        layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
+    } else {
+        load_chunk(ring[0], p.w2, lane);
+        load_chunk(ring[1], p.w2 + (size_t)NT1 * 256, lane);
+        // input channel k = 2s + h of this lane: dx, dy, dz, then the point's features
+        float x[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 2 * s + h;
+            float v = 0.f;
+            if (k < 3) v = src[k] - ctr[k];
+            else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid) * (long)p.cf + k - 3];
+            x[s] = v;
+        }
+        layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
+        layer_t<NT1, NT2, 0>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
+        constexpr int P2 = ((NT2 / 2) * NT1) & 1;
+        layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
+    }
+}
+
 // w (cin,cout) row-major -> 4 KiB chunks for the register chains, one per
 // (32-row input tile j, 32-column output tile t):
 //   element (q, lane, i) of a chunk = w[32j + 8q + 4(lane>>5) + i][32t + (lane&31)]
@@ -628,6 +721,15 @@ __global__ void tile_weights_reg_kernel(int cin, int cout, int jmajor, const flo
         const int k = 32 * j + 8 * q + 4 * (l >> 5) + i, col = 32 * t + (l & 31);
         wt[e] = w[(long)k * cout + col];
     }
+}
+
+template <int NJF, int NT1, int NT2, int NT3>
+int launch_sa_chain(const SaChainParams &p, hipStream_t st)
+{
+    const long waves = p.rows / 32;
+    hipLaunchKernelGGL((sa_chain_kernel<NJF, NT1, NT2, NT3>), dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)),
+                       dim3(64 * kRegWaves), 0, st, p);
+    return check_launch("fpn_sa_chain_f32");
 }
 
 }  // namespace
@@ -668,6 +770,44 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
     hipLaunchKernelGGL(seg_tail_reg_kernel, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
                        as_stream(stream), p);
     return check_launch("fpn_v1_seg_tail_f32");
+}
+
+int fpn_sa_chain_supported(int cf, int c1, int c2, int c3)
+{
+    const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32, t3 = c3 / 32;
+    if (cf >= 32 ? cf % 32 != 0 : cf > 5) return 0;
+    if (c1 % 64 || c2 % 64 || c3 % 128) return 0;
+    return (njf == 0 && t1 == 2 && t2 == 2 && t3 == 4) || (njf == 0 && t1 == 2 && t2 == 4 && t3 == 4) ||
+           (njf == 10 && t1 == 2 && t2 == 2 && t3 == 4) || (njf == 10 && t1 == 4 && t2 == 4 && t3 == 8) ||
+           (njf == 4 && t1 == 4 && t2 == 4 && t3 == 8);
+}
+
+int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                     const float *new_xyz, const float *feat, const int *idx, const float *const *layers,
+                     float *out, int ldo, int c3_valid, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 1 && m >= 1 && ns >= 1 && cf >= 0, "sa_chain: bad size");
+    FPN_REQUIRE(ns % 32 == 0, "sa_chain: samples per ball (%d) must be a multiple of 32", ns);
+    FPN_REQUIRE(c3_valid >= 1 && c3_valid <= c3 && ldo >= c3_valid, "sa_chain: bad output width %d (c3 %d, ld %d)", c3_valid, c3, ldo);
+    if (!fpn_sa_chain_supported(cf, c1, c2, c3))
+        return fail(FPN_E_UNSUPPORTED, "sa_chain: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
+    if (b == 0) return FPN_OK;
+    FPN_REQUIRE(xyz && new_xyz && idx && layers && out && (cf == 0 || feat), "sa_chain: null pointer");
+    for (int i = 0; i < 9; ++i) FPN_REQUIRE(layers[i], "sa_chain: layer parameter %d is null", i);
+    SaChainParams p{};
+    p.rows = (long)b * m * ns; p.n = n; p.m = m; p.ns = ns; p.cf = cf;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.idx = idx;
+    p.w1 = layers[0]; p.sc1 = layers[1]; p.sh1 = layers[2];
+    p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
+    p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
+    p.out = out; p.ldo = ldo; p.c3 = c3_valid;
+    const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32;
+    hipStream_t st = as_stream(stream);
+    if (njf == 0 && t2 == 2) return launch_sa_chain<0, 2, 2, 4>(p, st);
+    if (njf == 0) return launch_sa_chain<0, 2, 4, 4>(p, st);
+    if (njf == 10 && t1 == 2) return launch_sa_chain<10, 2, 2, 4>(p, st);
+    if (njf == 10) return launch_sa_chain<10, 4, 4, 8>(p, st);
+    return launch_sa_chain<4, 4, 4, 8>(p, st);
 }
 
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,

@@ -46,6 +46,8 @@ SIGNATURES = {
                                    _vp, _i, _vp, _sz, _vp],
     "fpn_max_pool_rows": [_l, _i, _i, _vp, _i, _vp, _i, _vp],
     "fpn_tile_weights_reg_f32": [_i, _i, _i, _vp, _vp, _vp],
+    "fpn_sa_chain_supported": [_i, _i, _i, _i],
+    "fpn_sa_chain_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],

@@ -21,6 +21,10 @@ from .tf_ops.tf_grouping import group_point, knn_point, query_ball_point
 from .tf_ops.tf_interpolate import three_nn_interpolate
 from .tf_ops.tf_sampling import farthest_point_sample, gather_point
 
+# Set-abstraction modules with max pooling and a three-layer MLP run as one fused kernel
+# when a kernel exists for their shape; False forces the per-layer path (used by tests).
+FUSE_SA = True
+
 
 def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
     """(B,N,3), (B,M,3), (B,N,C) or None, (B,M,ns) -> (B,M,ns,3+C): neighbour
@@ -69,6 +73,94 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     return new_xyz, new_points, idx, grouped_xyz
 
 
+def _layer_params(store, name, cin, cout, bn):
+    """Create (or fetch) the variables of one conv2d layer under `name` and return its
+    weight with the folded epilogue constants (scale may be None)."""
+    w = store.get_variable(name + "/weights", (cin, cout), "xavier")
+    store.get_variable(name + "/biases", (cout,), "zeros")
+    if bn:
+        store.get_variable(name + "/bn/gamma", (cout,), "ones")
+        store.get_variable(name + "/bn/beta", (cout,), "zeros")
+        store.get_variable(name + "/bn/moving_mean", (cout,), "zeros")
+        store.get_variable(name + "/bn/moving_variance", (cout,), "ones")
+    scale, shift = store.folded(name, bn)
+    return w, scale, shift
+
+
+def _round_up(v, q):
+    return (v + q - 1) // q * q
+
+
+def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
+    """Weights of a 3-layer set-abstraction MLP in the form fpn_sa_chain_f32 reads them
+    (padded widths, rows of the first layer reordered to [features | xyz] / [xyz |
+    features], chunked), or None when no fused kernel covers the shape.  Cached on the
+    store until its variables change."""
+    if len(widths) != 3:
+        return None
+    pad = (_round_up(widths[0], 64), _round_up(widths[1], 64), _round_up(widths[2], 128))
+    if not _lib.load().fpn_sa_chain_supported(cf, *pad):
+        # the variables are created by the per-layer path
+        return None
+    cache = store.__dict__.setdefault("_sa_chain_cache", {})
+    key = (names[0], cf, xyz_first)
+    hit = cache.get(key)
+    if hit is not None and hit["version"] == store.version:
+        return hit
+    cins = (3 + cf, widths[0], widths[1])
+    params = [_layer_params(store, names[i], cins[i], widths[i], bn) for i in range(3)]
+    version = store.version          # creating variables may have bumped it
+    dev = params[0][0].device
+
+    def padded(w, scale, shift, rows, cols):
+        wp = torch.zeros((rows, cols), dtype=torch.float32, device=dev)
+        wp[:w.shape[0], :w.shape[1]] = w
+        sp = torch.zeros(cols, dtype=torch.float32, device=dev)
+        sp[:w.shape[1]] = 1.0 if scale is None else scale
+        hp = torch.zeros(cols, dtype=torch.float32, device=dev)
+        hp[:w.shape[1]] = shift
+        return wp, sp, hp
+    w1, s1, h1 = params[0]
+    xyz_rows = w1[:3] if xyz_first else w1[cf:cf + 3]
+    feat_rows = w1[3:] if xyz_first else w1[:cf]
+    if cf >= 32:
+        w1k, s1p, h1p = padded(torch.cat([feat_rows, xyz_rows], 0), s1, h1, cf + 32, pad[0])
+        w1k = ops.tile_weights_reg(w1k, 0)
+    else:
+        w1k, s1p, h1p = padded(torch.cat([xyz_rows, feat_rows], 0), s1, h1, 3 + cf, pad[0])
+    w2p, s2p, h2p = padded(*params[1], pad[0], pad[1])
+    w3p, s3p, h3p = padded(*params[2], pad[1], pad[2])
+    tensors = [w1k.contiguous(), s1p, h1p, ops.tile_weights_reg(w2p, 0), s2p, h2p, ops.tile_weights_reg(w3p, 0), s3p, h3p]
+    plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "pad": pad}
+    cache[key] = plan
+    return plan
+
+
+def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first):
+    """Grouping + 3-layer MLP + max over the samples in one kernel (fpn_sa_chain_f32).
+    out2d (b*m, widths[-1]) may be a column slice of a wider buffer.  Returns False when
+    the shape has no fused kernel (the caller then runs the per-layer path)."""
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    cf = 0 if points is None else points.shape[2]
+    if ns % 32 != 0 or len(widths) != 3:
+        return False
+    store = variables.get_default_store()
+    names = [variables.scoped(scope_fmt % i) for i in range(3)]
+    plan = _sa_chain_plan(store, names, cf, widths, bn, xyz_first)
+    if plan is None:
+        return False
+    out2d.zero_()
+    pad = plan["pad"]
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.load().fpn_sa_chain_f32(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
+                                                _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx), plan["table"],
+                                                _lib.ptr(out2d), out2d.stride(0) if out2d.shape[0] > 1 else
+                                                max(out2d.stride(0), out2d.shape[1]), int(widths[2]),
+                                                _lib.stream_of(xyz)))
+    return True
+
+
 def _mlp_stack(x2d, widths, scope_fmt, bn, pool_rows=0, out=None):
     """Shared MLP over the rows of x2d; the pooling over groups of pool_rows rows is
     fused into the last layer when the kernel supports that group size.  `out`, if
@@ -77,15 +169,7 @@ def _mlp_stack(x2d, widths, scope_fmt, bn, pool_rows=0, out=None):
     fuse_pool = pool_rows and pool_rows % 32 == 0 and (pool_rows <= 128 and 128 % pool_rows == 0 or pool_rows % 128 == 0)
     for i, cout in enumerate(widths):
         name = variables.scoped(scope_fmt % i)
-        cin = x2d.shape[1]
-        w = store.get_variable(name + "/weights", (cin, cout), "xavier")
-        store.get_variable(name + "/biases", (cout,), "zeros")
-        if bn:
-            store.get_variable(name + "/bn/gamma", (cout,), "ones")
-            store.get_variable(name + "/bn/beta", (cout,), "zeros")
-            store.get_variable(name + "/bn/moving_mean", (cout,), "zeros")
-            store.get_variable(name + "/bn/moving_variance", (cout,), "ones")
-        scale, shift = store.folded(name, bn)
+        w, scale, shift = _layer_params(store, name, x2d.shape[1], cout, bn)
         last = i == len(widths) - 1
         x2d = ops.shared_mlp(x2d, w, scale, shift, relu=True, pool_rows=pool_rows if (last and fuse_pool) else 0,
                              out=out if (last and (fuse_pool or not pool_rows)) else None)
@@ -100,6 +184,18 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx (B,npoint,nsample)."""
     tf_util._inference_only(is_training)
     with variables.variable_scope(scope):
+        if not group_all and pooling == 'max' and mlp2 is None and FUSE_SA and (points is None or use_xyz):
+            # grouping, MLP and max-pool in one kernel (:106-126) when the shape has one
+            xyz = xyz.contiguous()
+            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+            if knn:
+                _, idx = knn_point(nsample, xyz, new_xyz)
+            else:
+                idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            pooled = torch.empty((xyz.shape[0] * npoint, mlp[-1]), dtype=torch.float32, device=xyz.device)
+            if _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx.contiguous(), mlp,
+                         'conv%d', bn, pooled, xyz_first=True):
+                return new_xyz, pooled.reshape(xyz.shape[0], npoint, -1), idx
         if group_all:
             nsample = xyz.shape[1]
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
@@ -143,6 +239,12 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         col = 0
         for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
             idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            w_i = mlp_list[i][-1]
+            if (points is None or use_xyz) and FUSE_SA and \
+                    _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx, mlp_list[i],
+                              'conv%d_' % i + '%d', bn, out[:, col:col + w_i], xyz_first=False):   # :176-192 in one kernel
+                col += w_i
+                continue
             if points is not None and use_xyz:
                 grouped = group_concat(xyz, new_xyz, points.contiguous(), idx, xyz_first=False)   # :183
             elif points is not None:
@@ -150,7 +252,6 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             else:
                 grouped = group_concat(xyz, new_xyz, None, idx)
             x2d = grouped.reshape(b * m * nsample, grouped.shape[-1])
-            w_i = mlp_list[i][-1]
             _mlp_stack(x2d, mlp_list[i], 'conv%d_' % i + '%d', bn, pool_rows=nsample,
                        out=out[:, col:col + w_i])                                                  # :187-194
             col += w_i

@@ -295,6 +295,33 @@ int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const floa
                          const float *const *layers, float *feat_max, int ldg, void *stream);
 
 /*
+ * Set-abstraction module with max pooling as ONE kernel: the grouping of
+ * sample_and_group (models/pointnet_util.py:36-51: group_point of xyz, translation
+ * to the centroid, group_point of the features, concat) or of the MSG loop
+ * (:176-186), the three conv2d layers of the module's MLP (:116-121 / :187-191)
+ * and the max over the nsample axis (:126 / :192).  A wave takes 32 consecutive
+ * samples of one ball and keeps every activation in registers (see
+ * fpn_v1_seg_tail_f32); the (b,m,nsample,3+cf) grouped tensor is never written.
+ *   xyz (b,n,3), new_xyz (b,m,3), feat (b,n,cf) or NULL, idx (b,m,ns) from
+ *   fpn_query_ball_point; ns % 32 == 0.
+ *   Layer widths c1, c2 (multiples of 64) and c3 (multiple of 128) are the PADDED
+ *   widths: a narrower layer is padded by the caller with zero weight columns and
+ *   zero scale / shift.  layers: HOST array of 9 device pointers {w,scale,shift} x 3:
+ *     cf < 32 : w1 row-major (3+cf, c1), rows ordered [dx,dy,dz, features];
+ *     cf >= 32: cf % 32 == 0, w1 = fpn_tile_weights_reg_f32(jmajor = 0) of the
+ *               (cf+32, c1) matrix whose rows are [features, dx,dy,dz, 29 zero rows];
+ *     w2 (c1,c2), w3 (c2,c3) in fpn_tile_weights_reg_f32 layout, jmajor = 0.
+ *   out (b*m, ldo): columns [0, c3_valid) of row (frustum, ball) receive the running
+ *   maximum (atomic max; the caller zeroes them first).  c3_valid <= c3.
+ * fpn_sa_chain_supported tells whether a kernel exists for the padded shape
+ * (FPN_E_UNSUPPORTED from fpn_sa_chain_f32 otherwise: use the per-layer path).
+ */
+int fpn_sa_chain_supported(int cf, int c1, int c2, int c3);
+int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                     const float *new_xyz, const float *feat, const int *idx,
+                     const float *const *layers, float *out, int ldo, int c3_valid, void *stream);
+
+/*
  * Mask, masked centroid and object-point gather of point_cloud_masking +
  * tf_gather_object_pc (models/model_util.py:275-319, :55-86), on the device
  * (the reference leaves the graph for numpy through tf.py_func, :84):

@@ -139,3 +139,53 @@ def test_v2_get_model_config2(device):
     out = P.v2_box_estimation(obj - gdelta[:, None, :], one_hot, params, M2.CONFIG)
     close(ep["box_output"].cpu().numpy(), out)
     assert ep["center"].shape == (3, 3) and ep["size_residuals"].shape == (3, 8, 3)
+
+
+def test_sa_chain_kernels(device):
+    """Every shape the fused set-abstraction kernel is built for (grouping + 3-layer MLP +
+    max over the samples in one launch) against the numpy oracle and against the
+    per-layer path; includes widths that are padded inside (32, 96, 64-wide outputs),
+    both concatenation orders and feature widths 0, 1, 128, 320."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(0)
+    b = 2
+    xyz_big = rng.uniform(0, 1, (b, 1024, 3)).astype(np.float32)
+    xyz_small = rng.uniform(0, 1, (b, 128, 3)).astype(np.float32)
+    cases = [
+        ("msg", xyz_big, rng.standard_normal((b, 1024, 1)).astype(np.float32),
+         (64, [0.1, 0.2, 0.4], [32, 64, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]])),
+        ("msg", xyz_small, rng.standard_normal((b, 128, 320)).astype(np.float32),
+         (32, [0.4, 0.8, 1.6], [64, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]])),
+        ("ssg", xyz_big, None, (64, 0.2, 64, [64, 64, 128])),
+        ("ssg", xyz_small, rng.standard_normal((b, 128, 128)).astype(np.float32), (32, 0.4, 64, [128, 128, 256])),
+    ]
+    for kind, xyz, pts, args in cases:
+        st = fresh_store(device, seed=len(args[-1]))
+        outs = {}
+        for fuse in (True, True, False):            # first pass creates the variables
+            U.FUSE_SA = fuse
+            try:
+                with variables.use_store(st):
+                    p = None if pts is None else dev(pts, device)
+                    if kind == "msg":
+                        new_xyz, feat = U.pointnet_sa_module_msg(dev(xyz, device), p, *args, False, None, scope='s')
+                    else:
+                        new_xyz, feat, _ = U.pointnet_sa_module(dev(xyz, device), p, *args, None, False, False, None,
+                                                                scope='s')
+            finally:
+                U.FUSE_SA = True
+            if "cache" not in outs:
+                assert "_sa_chain_cache" in st.__dict__ and len(st.__dict__["_sa_chain_cache"]) >= 1, "fused path not taken"
+                outs["cache"] = True
+                st.randomize_batch_norm(7)
+                continue
+            outs[fuse] = feat.cpu().numpy()
+        if kind == "msg":
+            wx, wf = P.sa_module_msg(xyz, pts, *args, st.numpy(), "s")
+        else:
+            wx, wf = P.sa_module(xyz, pts, *args, False, st.numpy(), "s")
+        np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx)
+        assert outs[True].shape == wf.shape
+        close(outs[True], wf)
+        close(outs[True], outs[False], 1e-4)
