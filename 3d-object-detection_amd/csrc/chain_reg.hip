@@ -529,11 +529,16 @@ struct SegHeadRegParams {
     int ldg;
 };
 
-__global__ __launch_bounds__(64 * kRegWaves) void seg_head_reg_kernel(const SegHeadRegParams p)
+// The head needs few enough registers for two waves per SIMD (two workgroups per CU).
+// 8-wave workgroups - both waves of a SIMD walking the weight stream together - were
+// measured slower (2.48 vs 2.36 ms): the two waves then also stall together.
+constexpr int kHeadWaves = kRegWaves;
+
+__global__ __launch_bounds__(64 * kHeadWaves) void seg_head_reg_kernel(const SegHeadRegParams p)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    const long row0 = ((long)blockIdx.x * kHeadWaves + (threadIdx.x >> 6)) * 32;
     if (row0 >= p.rows) return;
     float *gmax = p.gmax + (row0 / p.n) * p.ldg;
     FPN_STAMP(0);
@@ -828,7 +833,7 @@ int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float 
     p.w5 = reinterpret_cast<const float4 *>(layers[12]); p.sc5 = layers[13]; p.sh5 = layers[14];
     p.point_feat = point_feat; p.gmax = global_max; p.ldg = ldg;
     const long waves = rows / 32;
-    hipLaunchKernelGGL(seg_head_reg_kernel, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
+    hipLaunchKernelGGL(seg_head_reg_kernel, dim3((unsigned)((waves + kHeadWaves - 1) / kHeadWaves)), dim3(64 * kHeadWaves), 0,
                        as_stream(stream), p);
     return check_launch("fpn_v1_seg_head_f32");
 }

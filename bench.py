@@ -212,6 +212,15 @@ def side_config(args):
                 "ensemble statistics on device" % (args.samples, b_local, points)
         metric = "frustums/sec (node) FPointNet Bayes S=%d N=%d" % (args.samples, points)
     gathered = None
+    if args.graph:
+        from fpn.graph import GraphedForward
+        if args.config == "v2":
+            def fwd(pc_, oh_):
+                with variables.use_store(st):
+                    return fdist.pack_results(M2.get_model(pc_, oh_, False))
+            graphed = GraphedForward(fwd, [pc, one_hot])
+            step = lambda: graphed(pc, one_hot)       # noqa: E731
+        label += ", HIP-graph replay"
 
     def full_step():
         nonlocal gathered
@@ -262,6 +271,8 @@ def main():
                     help="v1: BASELINE config 1 (the headline metric, default); v2: PointNet++ variant, 2048 points "
                          "(config 2); bayes: Flipout v1 with --samples Monte-Carlo passes per frustum (config 3)")
     ap.add_argument("--samples", type=int, default=32, help="Monte-Carlo samples per frustum (--config bayes)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a HIP graph (side configs; removes the host launch overhead)")
     args = ap.parse_args()
     if args.config != "v1":
         return side_config(args)
