@@ -109,11 +109,22 @@ __device__ __forceinline__ void load_const(TileConst &c, const float *__restrict
     for (int q = 0; q < 4; ++q) c.q[q] = *reinterpret_cast<const float4 *>(p + ch0 + 8 * q);
 }
 
-// a = relu(a * sc + sh) in place
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// a = relu(a * sc + sh) in place.  The multiply-add is written on register pairs so that
+// it becomes v_pk_fma_f32 (two results per instruction): vector-ALU instructions issued
+// next to the MFMA stream are not free, each costs it a few cycles.
 __device__ __forceinline__ void bn_relu(floatx16 &a, const TileConst &sc, const TileConst &sh)
 {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r] * comp(sc.q[r >> 2], r & 3) + comp(sh.q[r >> 2], r & 3), 0.f);
+    for (int r = 0; r < 16; r += 2) {
+        const floatx2 v = {a[r], a[r + 1]};
+        const floatx2 s = {comp(sc.q[r >> 2], r & 3), comp(sc.q[r >> 2], (r & 3) + 1)};
+        const floatx2 b = {comp(sh.q[r >> 2], r & 3), comp(sh.q[r >> 2], (r & 3) + 1)};
+        const floatx2 y = v * s + b;
+        a[r] = fmaxf(y[0], 0.f);
+        a[r + 1] = fmaxf(y[1], 0.f);
+    }
 }
 
 // Order of one step of NMFMA MFMAs: after each MFMA one memory read (while there are
@@ -415,8 +426,13 @@ __device__ __forceinline__ void mfma_pair_n(floatx16 &acc_a, floatx16 &acc_b, co
 __device__ __forceinline__ void max_points(const floatx16 &acc, float sc, float sh, float *gmax, int h)
 {
     float m = 0.f;
+    const floatx2 s2 = {sc, sc}, b2 = {sh, sh};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[r] * sc + sh);
+    for (int r = 0; r < 16; r += 2) {     // v_pk_fma_f32 + v_max3_f32 per register pair
+        const floatx2 v = {acc[r], acc[r + 1]};
+        const floatx2 y = v * s2 + b2;
+        m = fmaxf(m, fmaxf(y[0], y[1]));
+    }
     // The two lane halves hold different points of the same channel.  Each issues its own
     // update: combining them first would cost a cross-lane exchange through the LDS pipe
     // whose wait stalls the MFMA stream, and a branch on the half would split the double
