@@ -159,6 +159,27 @@ def pointset_ops(dev, frustums=256, reps=20):
     return out
 
 
+REHEARSAL = os.environ.get("FPN_BENCH_BACKEND", "nccl") != "nccl"
+
+
+def init_rank(local_rank, world):
+    """One process per GPU: bind the rank's device and join the RCCL job (backend "nccl").
+    FPN_BENCH_BACKEND=gloo is a rehearsal switch for a box with fewer GPUs than ranks: the
+    ranks then share the visible devices round-robin and gather through gloo - it checks
+    the multi-rank control flow, its timings mean nothing."""
+    rehearsal = REHEARSAL
+    index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group(os.environ["FPN_BENCH_BACKEND"])
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return dev
+
+
 def side_config(args):
     """The other GPU workloads BASELINE names, with the same timing protocol as the
     headline one: --config v2 (PointNet++ variant: FPS + ball query + grouping + shared
@@ -169,11 +190,7 @@ def side_config(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dev = init_rank(local_rank, world)
     from fpn import dist as fdist
     from fpn import synthetic, variables
     if args.config == "v2":
@@ -282,11 +299,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dev = init_rank(local_rank, world)
 
     from fpn import dist as fdist
     from fpn import ops, plan, synthetic, variables
@@ -306,7 +319,10 @@ def main():
         ep = net.forward(pc, one_hot)
         rec = fdist.pack_results(ep)
         if world > 1:
-            fdist.gather_results(rec, out=gathered)
+            if REHEARSAL:       # gloo: collectives on host copies
+                fdist.gather_results(rec.cpu())
+            else:
+                fdist.gather_results(rec, out=gathered)
         return rec
 
     def fence():
@@ -326,7 +342,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.launch_observer = None
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
