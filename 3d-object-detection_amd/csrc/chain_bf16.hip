@@ -1,0 +1,642 @@
+// Register-resident layer chains on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16):
+// the same chains as chain_reg.hip - a wave carries 32 points through consecutive
+// shared-MLP layers, every layer computed transposed so that its result is already the
+// next layer's operand - with bf16 weights and bf16 activations between the layers and
+// fp32 accumulation.  Kept in fp32: the first layer of every stack (its inputs are
+// coordinates in metres, which bf16's 8 bits of mantissa would quantise to decimetres),
+// the batch-norm shifts, the maxima over points and the final 128 -> 2 layer.
+//
+// Operand shapes.  One MFMA contracts over 16 channels; lane (p = lane & 31,
+// h = lane >> 5) supplies 8 of them.  A 32 x 32 fp32 result tile (lane = point p,
+// register r = channel (r & 3) + 8 (r >> 2) + 4 h) becomes two operand fragments by
+// converting registers 8s .. 8s+7 (s = 0, 1) pairwise to bf16: element e of fragment s
+// is channel 16 s + 8 (e >> 2) + 4 h + (e & 3) of the tile.  The weight fragments are
+// laid out to match (fpn_chain_pack_bf16), with the batch-norm scale already multiplied
+// into the columns, so that an epilogue is: add the shift, clamp at zero, convert.
+//
+// Weight stream.  A UNIT is what one activation tile needs against a PAIR of output
+// tiles: 2 tiles x 2 fragments x 64 lanes x 16 bytes = 4 KiB, four MFMAs.  The units of
+// a kernel are stored back to back in exactly the order in which it consumes them
+// (layer by layer; inside a layer pair-major, input tile minor), followed by kPadUnits
+// units of padding, so that the kernel can always read a fixed number of units ahead -
+// across layer boundaries - through a ring of registers.
+#include <algorithm>
+#include <cstdint>
+#include <type_traits>
+#include <utility>
+
+#include "fpn_common.h"
+
+namespace fpn {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWaves = 4;          // waves per workgroup: they walk the weight stream together
+constexpr int kUnitVecs = 256;     // 16-byte vectors per unit
+constexpr int kPadUnits = 8;       // read-ahead beyond the last unit of a stream
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(std::forward<F>(f));
+    }
+}
+
+struct Act {            // 32 channels of the wave's 32 points as two operand fragments
+    bf16x8 m[2];
+};
+
+struct WUnit {          // [tile of the pair][fragment]
+    bf16x8 w[2][2];
+};
+
+__device__ __forceinline__ void load_unit(WUnit &u, const bf16x8 *__restrict__ p, unsigned lane)
+{
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) u.w[a][m] = p[(a * 2 + m) * 64 + lane];
+}
+
+// per-channel constants of a lane for one 32-channel tile: channels ch0 + 8q + i
+struct TileConst {
+    float4 q[4];
+};
+
+__device__ __forceinline__ float comp(const float4 &v, int i)
+{
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+__device__ __forceinline__ void load_const(TileConst &c, const float *__restrict__ p, int ch0)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.q[q] = *reinterpret_cast<const float4 *>(p + ch0 + 8 * q);
+}
+
+// relu(acc + shift) as the next layer's operand
+__device__ __forceinline__ void finish(Act &o, const floatx16 &a, const TileConst &sh)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        o.m[r >> 3][r & 7] = (__bf16)fmaxf(a[r] + comp(sh.q[r >> 2], r & 3), 0.f);
+}
+
+// ... or kept in fp32 (the layer before the final 128 -> 2 product)
+__device__ __forceinline__ void finish(floatx16 &o, const floatx16 &a, const TileConst &sh)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = fmaxf(a[r] + comp(sh.q[r >> 2], r & 3), 0.f);
+}
+
+__device__ __forceinline__ floatx16 mfma(const bf16x8 &a, const bf16x8 &b, const floatx16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// One unit: activation tile `act` against the two output tiles of the pair.  FIRST: the
+// accumulators start from zero (the hardware takes the constant, no register clearing).
+// T = true: transposed product (weights are the A operand, result lane = point);
+// T = false: lane = output channel, registers = points.
+template <bool FIRST, bool T>
+__device__ __forceinline__ void unit_mfma(floatx16 &acc_a, floatx16 &acc_b, const WUnit &u, const Act &act)
+{
+    const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (T) {
+        acc_a = mfma(u.w[0][0], act.m[0], FIRST ? z : acc_a);
+        acc_b = mfma(u.w[1][0], act.m[0], FIRST ? z : acc_b);
+        acc_a = mfma(u.w[0][1], act.m[1], acc_a);
+        acc_b = mfma(u.w[1][1], act.m[1], acc_b);
+    } else {
+        acc_a = mfma(act.m[0], u.w[0][0], FIRST ? z : acc_a);
+        acc_b = mfma(act.m[0], u.w[1][0], FIRST ? z : acc_b);
+        acc_a = mfma(act.m[1], u.w[0][1], acc_a);
+        acc_b = mfma(act.m[1], u.w[1][1], acc_b);
+    }
+}
+
+// Transposed layer: out[NT] = relu(W'^T . in[NJ] + shift), W' = W . diag(scale).
+// ws: the layer's first unit; the ring holds units [0, RING) of it on entry (slot
+// (R0 + i) % RING = unit i) and the first RING units after the layer on exit.  The
+// epilogue of a pair rides on the first two units of the next pair; the last one is
+// exposed.  Out: Act (bf16 operand) or floatx16 (fp32).
+template <int NJ, int NT, int R0, int RING, class Out>
+__device__ __forceinline__ void layer_t(Out (&out)[NT], const Act (&in)[NJ], const bf16x8 *__restrict__ ws,
+                                        const float *__restrict__ sh, WUnit (&ring)[RING], unsigned lane, int h)
+{
+    static_assert(NJ >= 2 && NT % 2 == 0, "unsupported layer shape");
+    constexpr int U = (NT / 2) * NJ;
+    floatx16 acc[2][2];
+    TileConst csh[2];
+    static_for<0, U>([&](auto I) {
+        constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
+        constexpr int slot = (R0 + S) % RING;
+        unit_mfma<j == 0, true>(acc[set][0], acc[set][1], ring[slot], in[j]);
+        load_unit(ring[slot], ws + (size_t)(S + RING) * kUnitVecs, lane);
+        if constexpr (tp > 0 && j < 2) finish(out[2 * (tp - 1) + j], acc[set ^ 1][j], csh[j]);
+        if constexpr (j == NJ - 1) {          // shifts of this pair, wanted one unit from now
+            load_const(csh[0], sh, 32 * (2 * tp) + 4 * h);
+            load_const(csh[1], sh, 32 * (2 * tp + 1) + 4 * h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    constexpr int last = (NT / 2 - 1) & 1;
+    finish(out[NT - 2], acc[last][0], csh[0]);
+    finish(out[NT - 1], acc[last][1], csh[1]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// max over the wave's points of relu(acc + shift) for the lane's channel, merged into
+// gmax[channel] with an integer atomic max (values >= +0 order like their bit patterns)
+__device__ __forceinline__ void max_points(const floatx16 &acc, float sh, float *gmax)
+{
+    float m = fmaxf(acc[0], acc[1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(acc[r], acc[r + 1]));
+    atomicMax(reinterpret_cast<int *>(gmax), __float_as_int(fmaxf(m + sh, 0.f)));
+}
+
+// Last layer of a stack: gmax[0 : 32 NT] = max(gmax, max over the 32 points of
+// relu(in[NJ] . W' + shift)), four output tiles per trip of a rolled loop; the
+// reduction of one pair rides on the units of the next.  Channels >= cvalid (widths
+// padded up to a multiple of 128) are not written.
+template <int NJ, int NT, int R0, int RING>
+__device__ __forceinline__ void layer_max(const Act (&in)[NJ], const bf16x8 *__restrict__ ws,
+                                          const float *__restrict__ sh, float *__restrict__ gmax,
+                                          WUnit (&ring)[RING], unsigned lane, int cvalid = 32 * NT)
+{
+    static_assert(NJ >= 2 && NT % 4 == 0 && (2 * NJ) % RING == 0, "unsupported layer shape");
+    const int c = lane & 31;
+    floatx16 acc[2][2];
+    const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc[1][0] = z;
+    acc[1][1] = z;
+    float rsh[2] = {0.f, 0.f};
+#pragma unroll 1
+    for (int t0 = 0; t0 < NT; t0 += 4) {
+        const bf16x8 *wt = ws + (size_t)(t0 / 2) * NJ * kUnitVecs;
+        static_for<0, 2 * NJ>([&](auto I) {
+            constexpr int S = decltype(I)::value, set = S / NJ, j = S % NJ;
+            constexpr int slot = (R0 + S) % RING;
+            unit_mfma<j == 0, false>(acc[set][0], acc[set][1], ring[slot], in[j]);
+            load_unit(ring[slot], wt + (size_t)(S + RING) * kUnitVecs, lane);
+            // the other accumulator pair holds the two tiles before these; the very first
+            // time there are none (it holds zeros, and so does the shift): the update is
+            // then a harmless max with 0 - no branch inside the unit
+            const int tcand = set == 0 ? t0 - 2 : t0;
+            const bool has_prev = (set == 1 || t0 > 0) && 32 * tcand < cvalid;
+            const int tprev = has_prev ? tcand : 0;
+            if constexpr (j < 2) max_points(acc[set ^ 1][j], has_prev ? rsh[j] : 0.f, gmax + 32 * (tprev + j) + c);
+            if constexpr (j == NJ - 1) {
+                const int tcur = t0 + 2 * set;
+                rsh[0] = sh[32 * tcur + c];
+                rsh[1] = sh[32 * (tcur + 1) + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    if (32 * (NT - 2) < cvalid) {
+        max_points(acc[1][0], rsh[0], gmax + 32 * (NT - 2) + c);
+        max_points(acc[1][1], rsh[1], gmax + 32 * (NT - 1) + c);
+    }
+}
+
+// First layer of a stack (K = 3..8 inputs straight from memory) on the fp32 matrix
+// instruction: out[NT] = relu(scale * (W1^T . x^T) + shift) as bf16 operands.  x: the
+// lane's inputs for MFMA steps 0..NSTEP-1, i.e. channels 2s + h of its point (zero beyond
+// the channel count); w1 (K, 32 NT) row-major fp32.
+template <int NT, int NSTEP>
+__device__ __forceinline__ void layer_first(Act (&out)[NT], const float (&x)[NSTEP], const float *__restrict__ w1,
+                                            int k_total, const float *__restrict__ sc, const float *__restrict__ sh,
+                                            unsigned lane, int h)
+{
+    const int c = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        floatx16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int k = 2 * s + h;
+            const float wv = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, x[s], a, 0, 0, 0);
+        }
+        TileConst csc, csh;
+        load_const(csc, sc, 32 * t + 4 * h);
+        load_const(csh, sh, 32 * t + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[t].m[r >> 3][r & 7] =
+                (__bf16)fmaxf(fmaf(a[r], comp(csc.q[r >> 2], r & 3), comp(csh.q[r >> 2], r & 3)), 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int RING>
+__device__ __forceinline__ void fill_ring(WUnit (&ring)[RING], const bf16x8 *__restrict__ ws, unsigned lane)
+{
+#pragma unroll
+    for (int i = 0; i < RING; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
+}
+
+constexpr int units_of(int cin, int cout) { return (cout / 64) * (cin / 32); }
+
+// ---------------------------------------------------------------------------
+// seg head: conv1 .. conv5 + max over points.  Stream: conv2, conv3, conv4, conv5.
+// point_feat (conv3's output) goes to memory as the tail's operand fragments: per point
+// 64 bf16, fragment (tile t, s) of lane half h at element ((2t + s) * 2 + h) * 8.
+// ---------------------------------------------------------------------------
+struct HeadParams {
+    long rows;
+    int n, cpc;
+    const float *pc;
+    const float *w1, *sc1, *sh1;
+    const bf16x8 *ws;
+    const float *sh2, *sh3, *sh4, *sh5;
+    bf16x8 *point_feat;
+    float *gmax;
+    int ldg;
+};
+
+constexpr int kHeadRing = 4;
+
+__global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+    float *gmax = p.gmax + (row0 / p.n) * p.ldg;
+
+    WUnit ring[kHeadRing];
+    fill_ring(ring, p.ws, lane);
+    float x[4];
+    const float *src = p.pc + (row0 + pt) * p.cpc;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
+    Act a1[2], a2[2], a3[2], a4[4];
+    layer_first<2, 4>(a1, x, p.w1, p.cpc, p.sc1, p.sh1, lane, h);
+    constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
+    const bf16x8 *ws = p.ws;
+    layer_t<2, 2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+    ws += U2 * kUnitVecs;
+    layer_t<2, 2, U2 % kHeadRing>(a3, a2, ws, p.sh3, ring, lane, h);
+    ws += U3 * kUnitVecs;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) p.point_feat[(row0 + pt) * 8 + (2 * t + s) * 2 + h] = a3[t].m[s];
+    layer_t<2, 4, (U2 + U3) % kHeadRing>(a4, a3, ws, p.sh4, ring, lane, h);
+    ws += U4 * kUnitVecs;
+    layer_max<4, 32, (U2 + U3 + U4) % kHeadRing>(a4, ws, p.sh5, gmax, ring, lane);
+}
+
+// ---------------------------------------------------------------------------
+// seg tail: conv6 (point part; the frustum part arrives as a per-frustum shift) ..
+// conv10.  Stream: conv6 (64 -> 512), conv7, conv8, conv9.
+// ---------------------------------------------------------------------------
+struct TailParams {
+    long rows;
+    int n;
+    const bf16x8 *point_feat;
+    const float *gshift;                 // (rows/n, 512)
+    const bf16x8 *ws;
+    const float *sh7, *sh8, *sh9;
+    const float *w10, *b10;              // (128,2), (2)
+    float *logits;                       // (rows,2)
+};
+
+constexpr int kTailRing = 8;
+
+__global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+
+    WUnit ring[kTailRing];
+    fill_ring(ring, p.ws, lane);
+    Act pf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pf[t].m[s] = p.point_feat[(row0 + pt) * 8 + (2 * t + s) * 2 + h];
+
+    constexpr int U6 = units_of(64, 512), U7 = units_of(512, 256), U8 = units_of(256, 128);
+    const bf16x8 *ws = p.ws;
+    Act a6[16], a7[8], a8[4];
+    floatx16 a9[4];
+    layer_t<2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, ring, lane, h);
+    ws += U6 * kUnitVecs;
+    layer_t<16, 8, U6 % kTailRing>(a7, a6, ws, p.sh7, ring, lane, h);
+    ws += U7 * kUnitVecs;
+    layer_t<8, 4, (U6 + U7) % kTailRing>(a8, a7, ws, p.sh8, ring, lane, h);
+    ws += U8 * kUnitVecs;
+    layer_t<4, 4, (U6 + U7 + U8) % kTailRing>(a9, a8, ws, p.sh9, ring, lane, h);
+
+    // conv10 (128 -> 2, no batch norm, no ReLU) on the vector ALU in fp32: each lane half
+    // sums its 64 channels, the halves meet through one cross-lane exchange
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 *w = reinterpret_cast<const float4 *>(p.w10 + (32 * j + 8 * q + 4 * h) * 2);
+            const float4 wa = w[0], wb = w[1];
+            s0 = fmaf(a9[j][4 * q + 0], wa.x, s0); s1 = fmaf(a9[j][4 * q + 0], wa.y, s1);
+            s0 = fmaf(a9[j][4 * q + 1], wa.z, s0); s1 = fmaf(a9[j][4 * q + 1], wa.w, s1);
+            s0 = fmaf(a9[j][4 * q + 2], wb.x, s0); s1 = fmaf(a9[j][4 * q + 2], wb.y, s1);
+            s0 = fmaf(a9[j][4 * q + 3], wb.z, s0); s1 = fmaf(a9[j][4 * q + 3], wb.w, s1);
+        }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    if (h == 0) *reinterpret_cast<float2 *>(p.logits + (row0 + pt) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
+}
+
+// ---------------------------------------------------------------------------
+// object-point stacks.  Stream: layer 2, layer 3 (, layer 4).
+// ---------------------------------------------------------------------------
+struct ObjParams {
+    long rows;
+    int m;
+    const float *obj, *delta;
+    const float *w1, *sc1, *sh1;       // (3,128) fp32
+    const bf16x8 *ws;
+    const float *sh2, *sh3, *sh4;
+    float *gmax;
+    int ldg;
+};
+
+constexpr int kObjRing = 4;
+
+template <bool BOX>
+__global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+    const long frustum = row0 / p.m;
+    float *gmax = p.gmax + frustum * p.ldg;
+
+    WUnit ring[kObjRing];
+    fill_ring(ring, p.ws, lane);
+    float x[2];
+    const float *src = p.obj + (row0 + pt) * 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int k = 2 * s + h;
+        x[s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
+    }
+    Act a1[4], a2[4];
+    layer_first<4, 2>(a1, x, p.w1, 3, p.sc1, p.sh1, lane, h);
+    constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
+    const bf16x8 *ws = p.ws;
+    layer_t<4, 4, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+    ws += U2 * kUnitVecs;
+    if constexpr (!BOX) {
+        layer_max<4, 8, U2 % kObjRing>(a2, ws, p.sh3, gmax, ring, lane);
+    } else {
+        Act a3[8];
+        layer_t<4, 8, U2 % kObjRing>(a3, a2, ws, p.sh3, ring, lane, h);
+        ws += U3 * kUnitVecs;
+        layer_max<8, 16, (U2 + U3) % kObjRing>(a3, ws, p.sh4, gmax, ring, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Set-abstraction module (models/pointnet_util.py:86-195) as one kernel, as
+// sa_chain_kernel of chain_reg.hip.  NJF > 0: the gathered point features are the first
+// layer's operand tiles (converted to bf16 on the way in) and the relative coordinates
+// ride in one more tile; stream: layer 1 ((NJF+1)*32 rows), layer 2, layer 3.
+// NJF = 0: first layer in fp32 from memory; stream: layer 2, layer 3.
+// ---------------------------------------------------------------------------
+struct SaParams {
+    long rows;
+    int n, m, ns, cf;
+    const float *xyz, *new_xyz, *feat;
+    const int *idx;
+    const float *w1, *sc1, *sh1;        // NJF = 0 only: (3+cf, 32 NT1) fp32, scale, shift
+    const bf16x8 *ws;
+    const float *shs1, *sh2, *sh3;      // shifts of the streamed layers (shs1: NJF > 0 only)
+    float *out;
+    int ldo, c3;
+};
+
+constexpr int kSaRing = 4;
+
+template <int NJF, int NT1, int NT2, int NT3>
+__global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaParams p)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+    const long ball = row0 / p.ns;
+    const long b = ball / p.m;
+    const int pid = p.idx[row0 + pt];
+    const float *ctr = p.new_xyz + ball * 3;
+    const float *src = p.xyz + (b * p.n + pid) * 3;
+    float *gmax = p.out + ball * p.ldo;
+
+    WUnit ring[kSaRing];
+    fill_ring(ring, p.ws, lane);
+    const bf16x8 *ws = p.ws;
+    Act a1[NT1], a2[NT2];
+    if constexpr (NJF > 0) {
+        constexpr int NJ1 = NJF + 1;
+        Act in[NJ1];
+        const float *f = p.feat + (b * p.n + pid) * (long)p.cf;
+#pragma unroll
+        for (int t = 0; t < NJF; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(f + 32 * t + 8 * q + 4 * h);
+                in[t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
+                in[t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
+                in[t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
+                in[t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
+            }
+        // channels 0..2 of the last tile: elements 0..2 of fragment 0 in the lower lane half
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) in[NJF].m[s][e] = (__bf16)0.f;
+        in[NJF].m[0][0] = (__bf16)(h == 0 ? src[0] - ctr[0] : 0.f);
+        in[NJF].m[0][1] = (__bf16)(h == 0 ? src[1] - ctr[1] : 0.f);
+        in[NJF].m[0][2] = (__bf16)(h == 0 ? src[2] - ctr[2] : 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int U1 = (NT1 / 2) * NJ1, U2 = (NT2 / 2) * NT1;
+        layer_t<NJ1, NT1, 0>(a1, in, ws, p.shs1, ring, lane, h);
+        ws += U1 * kUnitVecs;
+        layer_t<NT1, NT2, U1 % kSaRing>(a2, a1, ws, p.sh2, ring, lane, h);
+        ws += U2 * kUnitVecs;
+        layer_max<NT2, NT3, (U1 + U2) % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+    } else {
+        float x[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 2 * s + h;
+            float v = 0.f;
+            if (k < 3) v = src[k] - ctr[k];
+            else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid) * (long)p.cf + k - 3];
+            x[s] = v;
+        }
+        layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
+        constexpr int U2 = (NT2 / 2) * NT1;
+        layer_t<NT1, NT2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+        ws += U2 * kUnitVecs;
+        layer_max<NT2, NT3, U2 % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+    }
+}
+
+// w (cin,cout) fp32 row-major, scale (cout) or NULL -> the layer's units:
+// element e of fragment (unit (tp, j), tile u of the pair, k-fragment s, lane (h, c)) =
+//   bf16( w[32 j + 16 s + 8 (e >> 2) + 4 h + (e & 3)][32 (2 tp + u) + c] * scale[col] ),
+// units in the order tp * (cin/32) + j.
+__global__ void pack_units_kernel(int cin, int cout, const float *__restrict__ w, const float *__restrict__ scale,
+                                  __bf16 *__restrict__ dst)
+{
+    const long total = (long)cin * cout;
+    const int nj = cin / 32;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = i & 7, l = (i >> 3) & 63, s = (i >> 9) & 1, u = (i >> 10) & 1;
+        const long unit = i >> 11;
+        const int tp = (int)(unit / nj), j = (int)(unit % nj);
+        const int k = 32 * j + 16 * s + 8 * (e >> 2) + 4 * (l >> 5) + (e & 3), col = 32 * (2 * tp + u) + (l & 31);
+        const float v = w[(long)k * cout + col] * (scale ? scale[col] : 1.f);
+        dst[i] = (__bf16)v;
+    }
+}
+
+template <int NJF, int NT1, int NT2, int NT3>
+int launch_sa(const SaParams &p, hipStream_t st)
+{
+    const long waves = p.rows / 32;
+    hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3>), dim3((unsigned)((waves + kWaves - 1) / kWaves)),
+                       dim3(64 * kWaves), 0, st, p);
+    return check_launch("fpn_sa_chain_bf16");
+}
+
+}  // namespace
+}  // namespace fpn
+
+using namespace fpn;
+
+extern "C" {
+
+int fpn_chain_pad_units_bf16(void) { return kPadUnits; }
+
+int fpn_chain_pack_bf16(int cin, int cout, const float *w, const float *scale, void *units, void *stream)
+{
+    FPN_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 64 && cout % 64 == 0,
+                "chain_pack_bf16: cin (%d) must be a multiple of 32 and cout (%d) of 64", cin, cout);
+    FPN_REQUIRE(w && units, "chain_pack_bf16: null pointer");
+    const long total = (long)cin * cout;
+    hipLaunchKernelGGL(pack_units_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       as_stream(stream), cin, cout, w, scale, reinterpret_cast<__bf16 *>(units));
+    return check_launch("fpn_chain_pack_bf16");
+}
+
+int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void *wstream, const float *const *consts,
+                         void *point_feat, float *global_max, int ldg, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && n >= 1 && cpc >= 3 && cpc <= 8, "v1_seg_head_bf16: bad size rows=%ld n=%d cpc=%d", rows, n, cpc);
+    FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_head_bf16: points per frustum (%d) must be a multiple of 32", n);
+    FPN_REQUIRE(ldg >= 1024, "v1_seg_head_bf16: leading dimension of global_max (%d) must be >= 1024", ldg);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(pc && wstream && consts && point_feat && global_max, "v1_seg_head_bf16: null pointer");
+    for (int i = 0; i < 7; ++i) FPN_REQUIRE(consts[i], "v1_seg_head_bf16: constant %d is null", i);
+    HeadParams p{};
+    p.rows = rows; p.n = n; p.cpc = cpc; p.pc = pc;
+    p.w1 = consts[0]; p.sc1 = consts[1]; p.sh1 = consts[2];
+    p.ws = reinterpret_cast<const bf16x8 *>(wstream);
+    p.sh2 = consts[3]; p.sh3 = consts[4]; p.sh4 = consts[5]; p.sh5 = consts[6];
+    p.point_feat = reinterpret_cast<bf16x8 *>(point_feat); p.gmax = global_max; p.ldg = ldg;
+    const long waves = rows / 32;
+    hipLaunchKernelGGL(seg_head_bf16_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(64 * kWaves), 0,
+                       as_stream(stream), p);
+    return check_launch("fpn_v1_seg_head_bf16");
+}
+
+int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *group_shift, const void *wstream,
+                         const float *const *consts, float *logits, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && n >= 1, "v1_seg_tail_bf16: bad size");
+    FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_tail_bf16: points per frustum (%d) must be a multiple of 32", n);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(point_feat && group_shift && wstream && consts && logits, "v1_seg_tail_bf16: null pointer");
+    for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "v1_seg_tail_bf16: constant %d is null", i);
+    TailParams p{};
+    p.rows = rows; p.n = n; p.point_feat = reinterpret_cast<const bf16x8 *>(point_feat); p.gshift = group_shift;
+    p.ws = reinterpret_cast<const bf16x8 *>(wstream);
+    p.sh7 = consts[0]; p.sh8 = consts[1]; p.sh9 = consts[2]; p.w10 = consts[3]; p.b10 = consts[4];
+    p.logits = logits;
+    const long waves = rows / 32;
+    hipLaunchKernelGGL(seg_tail_bf16_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(64 * kWaves), 0,
+                       as_stream(stream), p);
+    return check_launch("fpn_v1_seg_tail_bf16");
+}
+
+int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const float *delta, const void *wstream,
+                          const float *const *consts, float *feat_max, int ldg, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && m >= 1, "v1_obj_chain_bf16: bad size");
+    FPN_REQUIRE(m % 32 == 0 && rows % m == 0, "v1_obj_chain_bf16: object points per frustum (%d) must be a multiple of 32", m);
+    FPN_REQUIRE(ldg >= (box ? 512 : 256), "v1_obj_chain_bf16: leading dimension of feat_max (%d) too small", ldg);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(obj && wstream && consts && feat_max, "v1_obj_chain_bf16: null pointer");
+    const int nc = box ? 6 : 5;
+    for (int i = 0; i < nc; ++i) FPN_REQUIRE(consts[i], "v1_obj_chain_bf16: constant %d is null", i);
+    ObjParams p{};
+    p.rows = rows; p.m = m; p.obj = obj; p.delta = delta;
+    p.w1 = consts[0]; p.sc1 = consts[1]; p.sh1 = consts[2];
+    p.ws = reinterpret_cast<const bf16x8 *>(wstream);
+    p.sh2 = consts[3]; p.sh3 = consts[4]; p.sh4 = box ? consts[5] : nullptr;
+    p.gmax = feat_max; p.ldg = ldg;
+    const long waves = rows / 32;
+    const dim3 grid((unsigned)((waves + kWaves - 1) / kWaves));
+    if (box) hipLaunchKernelGGL(obj_chain_bf16_kernel<true>, grid, dim3(64 * kWaves), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(obj_chain_bf16_kernel<false>, grid, dim3(64 * kWaves), 0, as_stream(stream), p);
+    return check_launch("fpn_v1_obj_chain_bf16");
+}
+
+int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                      const float *new_xyz, const float *feat, const int *idx, const void *wstream,
+                      const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 1 && m >= 1 && ns >= 1 && cf >= 0, "sa_chain_bf16: bad size");
+    FPN_REQUIRE(ns % 32 == 0, "sa_chain_bf16: samples per ball (%d) must be a multiple of 32", ns);
+    FPN_REQUIRE(c3_valid >= 64 && c3_valid % 64 == 0 && c3_valid <= c3 && ldo >= c3_valid,
+                "sa_chain_bf16: bad output width %d (c3 %d, ld %d)", c3_valid, c3, ldo);
+    if (!fpn_sa_chain_supported(cf, c1, c2, c3))
+        return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
+    if (b == 0) return FPN_OK;
+    FPN_REQUIRE(xyz && new_xyz && idx && wstream && consts && out && (cf == 0 || feat), "sa_chain_bf16: null pointer");
+    const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32;
+    SaParams p{};
+    p.rows = (long)b * m * ns; p.n = n; p.m = m; p.ns = ns; p.cf = cf;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.idx = idx;
+    p.ws = reinterpret_cast<const bf16x8 *>(wstream);
+    if (njf == 0) {       // consts: w1, scale1, shift1, shift2, shift3
+        for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "sa_chain_bf16: constant %d is null", i);
+        p.w1 = consts[0]; p.sc1 = consts[1]; p.sh1 = consts[2]; p.sh2 = consts[3]; p.sh3 = consts[4];
+    } else {              // consts: shift1, shift2, shift3
+        for (int i = 0; i < 3; ++i) FPN_REQUIRE(consts[i], "sa_chain_bf16: constant %d is null", i);
+        p.shs1 = consts[0]; p.sh2 = consts[1]; p.sh3 = consts[2];
+    }
+    p.out = out; p.ldo = ldo; p.c3 = c3_valid;
+    hipStream_t st = as_stream(stream);
+    if (njf == 0 && t2 == 2) return launch_sa<0, 2, 2, 4>(p, st);
+    if (njf == 0) return launch_sa<0, 2, 4, 4>(p, st);
+    if (njf == 10 && t1 == 2) return launch_sa<10, 2, 2, 4>(p, st);
+    if (njf == 10) return launch_sa<10, 4, 4, 8>(p, st);
+    return launch_sa<4, 4, 4, 8>(p, st);
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpn_hip.so")
 
 FPN_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class FpnError(RuntimeError):
@@ -51,6 +51,12 @@ SIGNATURES = {
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "fpn_chain_pad_units_bf16": [],
+    "fpn_chain_pack_bf16": [_i, _i, _vp, _vp, _vp, _vp],
+    "fpn_v1_seg_head_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "fpn_v1_seg_tail_bf16": [_l, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fpn_v1_obj_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "fpn_sa_chain_bf16": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_box3d_iou_f64": [_l, _vp, _l, _vp, _l, _vp, _vp],
     "fpn_box3d_best_overlap_f64": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -168,6 +168,69 @@ def v1_obj_chain(obj2d, m, box, delta, table, feat_max):
         obs.end(tok)
 
 
+def chain_stream_bf16(layers):
+    """The weight stream of a bf16 chain kernel: `layers` is the list of (w (cin,cout)
+    fp32, folded batch-norm scale (cout,) or None) in the order the kernel runs them;
+    returns one bfloat16 tensor (fpn_chain_pack_bf16 per layer, back to back, plus the
+    read-ahead padding)."""
+    lib = _lib.load()
+    dev = layers[0][0].device
+    pad = lib.fpn_chain_pad_units_bf16() * 2048
+    out = torch.zeros(sum(w.shape[0] * w.shape[1] for w, _ in layers) + pad, dtype=torch.bfloat16, device=dev)
+    off = 0
+    with torch.cuda.device(dev):
+        for w, scale in layers:
+            _lib.require_device_tensor("w", w, torch.float32, 2)
+            cin, cout = w.shape
+            _lib.check(lib.fpn_chain_pack_bf16(cin, cout, _lib.ptr(w), _lib.ptr(scale),
+                                               ctypes.c_void_p(out.data_ptr() + 2 * off), _lib.stream_of(w)))
+            off += cin * cout
+    return out
+
+
+def v1_seg_head_bf16(pc2d, n, wstream, consts, point_feat, global_max):
+    """fpn_v1_seg_head_bf16: as v1_seg_head; point_feat (rows,64) bfloat16."""
+    rows, cpc = pc2d.shape
+    obs = launch_observer
+    tok = obs.begin("v1_seg_head_bf16", rows, 0, 0, macs=rows * (cpc * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024)) \
+        if obs is not None else None
+    with torch.cuda.device(pc2d.device):
+        _lib.check(_lib.load().fpn_v1_seg_head_bf16(rows, int(n), cpc, _lib.ptr(pc2d), _lib.ptr(wstream), consts,
+                                                    _lib.ptr(point_feat), _lib.ptr(global_max), _ld(global_max),
+                                                    _lib.stream_of(pc2d)))
+    if obs is not None:
+        obs.end(tok)
+
+
+def v1_seg_tail_bf16(point_feat, n, gbias, wstream, consts, logits):
+    """fpn_v1_seg_tail_bf16: as v1_seg_tail on the bfloat16 point_feat of the bf16 head."""
+    rows = point_feat.shape[0]
+    obs = launch_observer
+    tok = obs.begin("v1_seg_tail_bf16", rows, 0, 0, macs=rows * (64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2)) \
+        if obs is not None else None
+    with torch.cuda.device(point_feat.device):
+        _lib.check(_lib.load().fpn_v1_seg_tail_bf16(rows, int(n), _lib.ptr(point_feat), _lib.ptr(gbias),
+                                                    _lib.ptr(wstream), consts, _lib.ptr(logits),
+                                                    _lib.stream_of(point_feat)))
+    if obs is not None:
+        obs.end(tok)
+
+
+def v1_obj_chain_bf16(obj2d, m, box, delta, wstream, consts, feat_max):
+    """fpn_v1_obj_chain_bf16: as v1_obj_chain."""
+    rows = obj2d.shape[0]
+    macs = 3 * 128 + 128 * 128 + 128 * 256 + (256 * 512 if box else 0)
+    obs = launch_observer
+    tok = obs.begin("v1_obj_chain_box_bf16" if box else "v1_obj_chain_tnet_bf16", rows, 0, 0, macs=rows * macs) \
+        if obs is not None else None
+    with torch.cuda.device(obj2d.device):
+        _lib.check(_lib.load().fpn_v1_obj_chain_bf16(rows, int(m), int(bool(box)), _lib.ptr(obj2d), _lib.ptr(delta),
+                                                     _lib.ptr(wstream), consts, _lib.ptr(feat_max), _ld(feat_max),
+                                                     _lib.stream_of(obj2d)))
+    if obs is not None:
+        obs.end(tok)
+
+
 def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True):
     """point_cloud (B,N,C>=3), logits (B,N,2) -> mask (B,N), mean (B,3), sel
     (B,npick) int32, obj (B,npick,3) through fpn_mask_gather."""

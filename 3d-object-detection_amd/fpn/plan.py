@@ -74,7 +74,12 @@ def init_variables(store, pc_channels=4, bn=True):
 
 
 class V1Plan:
-    def __init__(self, store, pc_channels=4, bn=True, chunk_frustums=None, chain=True):
+    def __init__(self, store, pc_channels=4, bn=True, chunk_frustums=None, chain=True, precision="fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+        if precision == "bf16" and not chain:
+            raise ValueError("bf16 exists for the layer-chain kernels only")
+        self.precision = precision    # operand type of the chain kernels' matrix products
         self.store = store
         self.pc_channels = pc_channels
         self.bn = bn
@@ -119,6 +124,26 @@ class V1Plan:
         self._tail_table = ops.pointer_table(self._tail_tensors)
         self._tnet_table = ops.pointer_table(self._tnet_tensors)
         self._box_table = ops.pointer_table(self._box_tensors)
+        if self.precision == "bf16":
+            # bf16 chains: one weight stream per kernel (batch-norm scale folded into the
+            # columns), fp32 first layers and shifts
+            P = self.p
+            def stream(scopes, first=None):
+                layers = [first] if first is not None else []
+                return ops.chain_stream_bf16(layers + [(P[s][0].contiguous(), P[s][1]) for s in scopes])
+            def consts(first, scopes, extra=()):
+                t = (reg(first, tiled=False) if first else []) + [P[s][2] for s in scopes] + list(extra)
+                return t, ops.pointer_table(t)
+            self._head_ws = stream(("conv2", "conv3", "conv4", "conv5"))
+            self._head_ct, self._head_consts = consts("conv1", ("conv2", "conv3", "conv4", "conv5"))
+            self._tail_ws = stream(("conv7", "conv8", "conv9"), first=(self.w6_pt, P["conv6"][1]))
+            self._tail_ct, self._tail_consts = consts(None, ("conv7", "conv8", "conv9"), (P["conv10"][0], P["conv10"][2]))
+            tn = [s for s, _ in TNET_CONV]
+            bx = [s for s, _ in BOX_CONV]
+            self._tnet_ws = stream(tn[1:])
+            self._tnet_ct, self._tnet_consts = consts(tn[0], tn[1:])
+            self._box_ws = stream(bx[1:])
+            self._box_ct, self._box_consts = consts(bx[0], bx[1:])
         self._version = st.version
 
     def _layer(self, x, scope, **kw):
@@ -164,16 +189,23 @@ class V1Plan:
         # --- instance segmentation net (frustum_pointnets_v1.py:20-90) -------------
         gcat = torch.empty((b, 1024 + 3), dtype=torch.float32, device=dev)
         gcat[:, 1024:] = one_hot                                        # concat one-hot :64
+        bf16 = self.precision == "bf16"
         if self.chain:
-            point_feat = torch.empty((rows, 64), dtype=torch.float32, device=dev)
+            point_feat = torch.empty((rows, 64), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
             gcat[:, :1024] = 0                    # the head kernel accumulates the maximum in place
-            ops.v1_seg_head(x, n, self._head_table, point_feat, gcat)      # conv1..conv5 + maxpool :41-61
+            if bf16:
+                ops.v1_seg_head_bf16(x, n, self._head_ws, self._head_consts, point_feat, gcat)
+            else:
+                ops.v1_seg_head(x, n, self._head_table, point_feat, gcat)  # conv1..conv5 + maxpool :41-61
             # frustum-constant part of conv6, folded into its shift:
             # ([global_feat | one_hot] . W6[64:]) * scale6 + shift6
             _, scale6, shift6, _ = self.p["conv6"]
             gbias = ops.shared_mlp(gcat, self.w6_glob, scale6, shift6, relu=False)
             logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
-            ops.v1_seg_tail(point_feat, n, gbias, self._tail_table, logits)       # conv6..conv10 :68-89
+            if bf16:
+                ops.v1_seg_tail_bf16(point_feat, n, gbias, self._tail_ws, self._tail_consts, logits)
+            else:
+                ops.v1_seg_tail(point_feat, n, gbias, self._tail_table, logits)   # conv6..conv10 :68-89
             del point_feat
         else:
             a = self._layer(x, "conv1")
@@ -202,7 +234,10 @@ class V1Plan:
         obj2d = obj.reshape(b * m, 3)
         if self.chain:
             tcat[:, :256] = 0
-            ops.v1_obj_chain(obj2d, m, False, None, self._tnet_table, tcat)     # conv stack + maxpool :335-347
+            if bf16:
+                ops.v1_obj_chain_bf16(obj2d, m, False, None, self._tnet_ws, self._tnet_consts, tcat)
+            else:
+                ops.v1_obj_chain(obj2d, m, False, None, self._tnet_table, tcat)   # conv stack + maxpool :335-347
         else:
             t = self._layer(obj2d, "conv-reg1-stage1")
             t = self._layer(t, "conv-reg2-stage1")
@@ -218,7 +253,10 @@ class V1Plan:
         if self.chain:
             # the kernel subtracts center_delta while loading the tile (:176-177)
             bcat[:, :512] = 0
-            ops.v1_obj_chain(obj2d, m, True, center_delta, self._box_table, bcat)   # :108-124
+            if bf16:
+                ops.v1_obj_chain_bf16(obj2d, m, True, center_delta, self._box_ws, self._box_consts, bcat)
+            else:
+                ops.v1_obj_chain(obj2d, m, True, center_delta, self._box_table, bcat)   # :108-124
         else:
             obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)     # :176-177
             t = self._layer(obj_new, "conv-reg1")

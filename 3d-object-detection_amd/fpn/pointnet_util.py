@@ -24,6 +24,9 @@ from .tf_ops.tf_sampling import farthest_point_sample, gather_point
 # Set-abstraction modules with max pooling and a three-layer MLP run as one fused kernel
 # when a kernel exists for their shape; False forces the per-layer path (used by tests).
 FUSE_SA = True
+# Operand type of the fused kernel's matrix products: "fp32", or "bf16" (bf16 weights and
+# activations between the layers, fp32 accumulation; the per-layer path stays fp32).
+SA_PRECISION = "fp32"
 
 
 def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
@@ -103,7 +106,7 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
         # the variables are created by the per-layer path
         return None
     cache = store.__dict__.setdefault("_sa_chain_cache", {})
-    key = (names[0], cf, xyz_first)
+    key = (names[0], cf, xyz_first, SA_PRECISION)
     hit = cache.get(key)
     if hit is not None and hit["version"] == store.version:
         return hit
@@ -130,8 +133,22 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
         w1k, s1p, h1p = padded(torch.cat([xyz_rows, feat_rows], 0), s1, h1, 3 + cf, pad[0])
     w2p, s2p, h2p = padded(*params[1], pad[0], pad[1])
     w3p, s3p, h3p = padded(*params[2], pad[1], pad[2])
-    tensors = [w1k.contiguous(), s1p, h1p, ops.tile_weights_reg(w2p, 0), s2p, h2p, ops.tile_weights_reg(w3p, 0), s3p, h3p]
-    plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "pad": pad}
+    if SA_PRECISION == "bf16":
+        # one bf16 weight stream (scales folded into the columns); fp32 first layer when
+        # it reads the coordinates and features straight from memory (cf < 32)
+        if cf >= 32:
+            w1p = padded(torch.cat([feat_rows, xyz_rows], 0), s1, h1, cf + 32, pad[0])[0]
+            stream = ops.chain_stream_bf16([(w1p, s1p), (w2p, s2p), (w3p, s3p)])
+            tensors = [h1p, h2p, h3p]
+        else:
+            stream = ops.chain_stream_bf16([(w2p, s2p), (w3p, s3p)])
+            tensors = [w1k.contiguous(), s1p, h1p, h2p, h3p]
+        plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "pad": pad,
+                "stream": stream}
+    else:
+        tensors = [w1k.contiguous(), s1p, h1p, ops.tile_weights_reg(w2p, 0), s2p, h2p, ops.tile_weights_reg(w3p, 0),
+                   s3p, h3p]
+        plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "pad": pad}
     cache[key] = plan
     return plan
 
@@ -152,12 +169,17 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
         return False
     out2d.zero_()
     pad = plan["pad"]
+    ldo = out2d.stride(0) if out2d.shape[0] > 1 else max(out2d.stride(0), out2d.shape[1])
     with torch.cuda.device(xyz.device):
-        _lib.check(_lib.load().fpn_sa_chain_f32(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
-                                                _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx), plan["table"],
-                                                _lib.ptr(out2d), out2d.stride(0) if out2d.shape[0] > 1 else
-                                                max(out2d.stride(0), out2d.shape[1]), int(widths[2]),
-                                                _lib.stream_of(xyz)))
+        if "stream" in plan:
+            _lib.check(_lib.load().fpn_sa_chain_bf16(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
+                                                     _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx),
+                                                     _lib.ptr(plan["stream"]), plan["table"], _lib.ptr(out2d), ldo,
+                                                     int(widths[2]), _lib.stream_of(xyz)))
+        else:
+            _lib.check(_lib.load().fpn_sa_chain_f32(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
+                                                    _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx), plan["table"],
+                                                    _lib.ptr(out2d), ldo, int(widths[2]), _lib.stream_of(xyz)))
     return True
 
 

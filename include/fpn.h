@@ -322,6 +322,52 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
                      const float *const *layers, float *out, int ldo, int c3_valid, void *stream);
 
 /*
+ * The same layer chains on the bf16 matrix instruction (fp32 accumulation): the
+ * shared MLPs of models/frustum_pointnets_v1.py:41-88,108-124, models/model_util.py:
+ * 335-347 and models/pointnet_util.py:116-126,187-192 with bf16 weights and bf16
+ * activations between the layers.  Kept in fp32: the first layer of every stack that
+ * reads coordinates from memory, all batch-norm shifts, the maxima over points and
+ * the last 128 -> 2 layer of the segmentation net.  Results differ from the fp32
+ * entry points by bf16 rounding (2^-9 relative per operand).
+ *
+ * Weights reach these kernels as one STREAM per kernel: for every layer after the
+ * first, fpn_chain_pack_bf16 turns w (cin,cout) fp32 - with the folded batch-norm
+ * scale multiplied into its columns (scale may be NULL = ones) - into
+ * cin*cout bf16 values in the order the kernel consumes them; the caller places the
+ * layers of a kernel back to back (the order is given with each entry point) and
+ * leaves fpn_chain_pad_units_bf16() * 4096 bytes of readable padding after the last
+ * one (the kernels read ahead).  cin % 32 == 0, cout % 64 == 0.
+ *   `consts`: HOST array of device pointers to the fp32 per-channel constants.
+ */
+int fpn_chain_pad_units_bf16(void);
+int fpn_chain_pack_bf16(int cin, int cout, const float *w, const float *scale, void *units,
+                        void *stream);
+/* stream: conv2, conv3, conv4, conv5; consts {w1 (cpc,64), scale1, shift1, shift2..shift5};
+ * point_feat (rows,64) bf16 in an internal operand order, only meaningful to
+ * fpn_v1_seg_tail_bf16; global_max as in fpn_v1_seg_head_f32. */
+int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void *wstream,
+                         const float *const *consts, void *point_feat, float *global_max, int ldg,
+                         void *stream);
+/* stream: conv6 rows 0..63, conv7, conv8, conv9; consts {shift7, shift8, shift9, w10
+ * (128,2), bias10}; group_shift as in fpn_v1_seg_tail_f32. */
+int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *group_shift,
+                         const void *wstream, const float *const *consts, float *logits,
+                         void *stream);
+/* stream: layer 2, layer 3 (, layer 4 when box != 0); consts {w1 (3,128), scale1,
+ * shift1, shift2, shift3 (, shift4)}. */
+int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const float *delta,
+                          const void *wstream, const float *const *consts, float *feat_max,
+                          int ldg, void *stream);
+/* Shapes and padding rules of fpn_sa_chain_f32; c3_valid % 64 == 0.
+ *   cf < 32 : stream: layer 2, layer 3; consts {w1 (3+cf,c1) fp32, scale1, shift1,
+ *             shift2, shift3};
+ *   cf >= 32: stream: layer 1 (rows [features, dx,dy,dz, 29 zero rows]), layer 2,
+ *             layer 3; consts {shift1, shift2, shift3}. */
+int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                      const float *new_xyz, const float *feat, const int *idx, const void *wstream,
+                      const float *const *consts, float *out, int ldo, int c3_valid, void *stream);
+
+/*
  * Mask, masked centroid and object-point gather of point_cloud_masking +
  * tf_gather_object_pc (models/model_util.py:275-319, :55-86), on the device
  * (the reference leaves the graph for numpy through tf.py_func, :84):

@@ -1,0 +1,154 @@
+"""GPU tests of the bf16 layer-chain kernels (bf16 weights and activations between the
+layers, fp32 accumulation, fp32 first layers / shifts / maxima / final layer).
+
+Two kinds of check:
+  * EXACT: with weights that only select and scale inputs (one non-zero per column,
+    small integers) and small-integer inputs every activation is an integer below 256
+    and therefore exact in bf16: the bf16 kernels must then agree with the fp32 kernels
+    BIT FOR BIT, which pins every operand layout (a wrong lane or channel order picks a
+    different input and shows);
+  * TOLERANCE: with random weights the bf16 results are compared with the float64
+    oracle under the stated looser bound BF16_RTOL: |got - want| <= BF16_RTOL *
+    max(|want|, rms(want)).  bf16 keeps 8 significant bits (relative rounding 2^-9 =
+    2e-3 per operand); through the 5..10 layers of a stack the observed error is
+    ~1e-2 of the output's scale, the bound leaves a factor ~3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import v1_numpy as V
+
+pytestmark = pytest.mark.gpu
+
+BF16_RTOL = 4e-2
+
+
+def scaled_err(got, want):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    s = np.sqrt(np.mean(want ** 2)) + 1e-30
+    return float((np.abs(got - want) / np.maximum(np.abs(want), s)).max())
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def selection_store(device, seed):
+    """v1 variables without batch norm whose weight matrices have one non-zero per
+    column: the first layers multiply an input by a small integer, every other layer
+    copies one of its inputs."""
+    from fpn import plan, variables
+    st = variables.VariableStore(device, seed=seed)
+    plan.init_variables(st, 4, bn=False)
+    rng = np.random.RandomState(seed)
+    for scope, cin, cout, _, _ in plan.layer_table(4):
+        w = np.zeros((cin, cout), np.float32)
+        cols = np.arange(cout)
+        if scope == "conv1":
+            w[cols % 4, cols] = cols // 4 + 1                # x <= 7, factor <= 16: values <= 112
+        elif scope in ("conv-reg1-stage1", "conv-reg1"):
+            w[cols % 3, cols] = 1 + (cols // 3) % 4
+        else:
+            w[rng.randint(0, cin, cout), cols] = 1
+        st[scope + "/weights"] = w
+    return st
+
+
+def test_bf16_chains_exact_on_integer_data(device):
+    from fpn import model_util, ops, plan
+    st = selection_store(device, 3)
+    f32 = plan.V1Plan(st, 4, False)
+    b16 = plan.V1Plan(st, 4, False, precision="bf16")
+    rng = np.random.RandomState(0)
+    for b_, n in ((3, 256), (2, 1024), (5, 96)):
+        pc = rng.randint(0, 8, (b_, n, 4)).astype(np.float32)
+        one_hot = np.eye(3, dtype=np.float32)[rng.randint(0, 3, b_)]
+        a = f32.forward(dev(pc, device), dev(one_hot, device))
+        c = b16.forward(dev(pc, device), dev(one_hot, device))
+        assert float(a["mask_logits"].abs().max()) > 0
+        assert torch.equal(a["mask_logits"], c["mask_logits"]), (b_, n)
+        # and against the oracle (exact as well: integers all the way)
+        want = V.get_model(pc, one_hot, st.numpy(), bn=False)
+        np.testing.assert_array_equal(c["mask_logits"].cpu().numpy(), want["mask_logits"])
+
+    # object-point stacks on integer coordinates, with and without the centre shift
+    m = model_util.NUM_OBJECT_POINT
+    for box in (False, True):
+        width = 512 if box else 256
+        for b_ in (1, 4):
+            obj = dev(rng.randint(0, 8, (b_ * m, 3)).astype(np.float32), device)
+            delta = dev(rng.randint(0, 4, (b_, 3)).astype(np.float32), device) if box else None
+            want = torch.zeros((b_, width + 3), device=device)
+            got = torch.zeros((b_, width + 3), device=device)
+            ops.v1_obj_chain(obj, m, box, delta, f32._box_table if box else f32._tnet_table, want)
+            ops.v1_obj_chain_bf16(obj, m, box, delta, b16._box_ws if box else b16._tnet_ws,
+                                  b16._box_consts if box else b16._tnet_consts, got)
+            assert float(want.abs().max()) > 0
+            assert torch.equal(want, got), (box, b_)
+
+
+def test_bf16_v1_within_stated_bound(device):
+    """Random weights and batch norm: logits, and everything after the mask (evaluated by
+    the oracle on the GPU's own mask), within BF16_RTOL of the float64 oracle."""
+    from fpn import plan, synthetic, variables
+    st = variables.VariableStore(device, seed=1)
+    plan.init_variables(st, 4, True)
+    st.randomize_batch_norm(2)
+    net = plan.V1Plan(st, 4, True, precision="bf16")
+    worst = {}
+    for b_, n in ((8, 1024), (3, 160)):
+        pc, one_hot = synthetic.make_frustums(b_, n, 4, seed=n)
+        ep = net.forward(dev(pc, device), dev(one_hot, device))
+        want = V.get_model(pc, one_hot, st.numpy(), dtype=np.float64)
+        worst["mask_logits"] = max(worst.get("mask_logits", 0), scaled_err(ep["mask_logits"].cpu().numpy(), want["mask_logits"]))
+        mask = ep["mask"].cpu().numpy()
+        want = V.get_model(pc, one_hot, st.numpy(), dtype=np.float64, mask_override=mask)
+        np.testing.assert_array_equal(ep["object_point_indices"].cpu().numpy(), want["object_point_indices"])
+        for k in ("center_delta", "stage1_center", "box_output", "center"):
+            worst[k] = max(worst.get(k, 0), scaled_err(ep[k].cpu().numpy(), want[k]))
+    print("bf16 scaled errors:", {k: "%.2e" % v for k, v in worst.items()})
+    assert max(worst.values()) <= BF16_RTOL, worst
+    assert worst["mask_logits"] > 1e-5, "suspiciously exact: is the bf16 path running?"
+
+
+def test_bf16_set_abstraction_within_stated_bound(device):
+    """The fused set-abstraction kernel in bf16 against its fp32 twin, every shape the v2
+    topology uses (features 0 / 1 / 128 / 320 wide, both concatenation orders)."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(0)
+    b = 2
+    xyz_big = rng.uniform(0, 1, (b, 1024, 3)).astype(np.float32)
+    xyz_small = rng.uniform(0, 1, (b, 128, 3)).astype(np.float32)
+    cases = [
+        ("msg", xyz_big, rng.standard_normal((b, 1024, 1)).astype(np.float32),
+         (64, [0.1, 0.2, 0.4], [32, 64, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]])),
+        ("msg", xyz_small, rng.standard_normal((b, 128, 320)).astype(np.float32),
+         (32, [0.4, 0.8, 1.6], [64, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]])),
+        ("ssg", xyz_big, None, (64, 0.2, 64, [64, 64, 128])),
+        ("ssg", xyz_small, rng.standard_normal((b, 128, 128)).astype(np.float32), (32, 0.4, 64, [128, 128, 256])),
+    ]
+    for kind, xyz, pts, args in cases:
+        st = variables.VariableStore(device, seed=5)
+        outs = {}
+        for precision in ("fp32", "fp32", "bf16"):     # first pass creates the variables
+            U.SA_PRECISION = precision
+            try:
+                with variables.use_store(st):
+                    p = None if pts is None else dev(pts, device)
+                    if kind == "msg":
+                        _, feat = U.pointnet_sa_module_msg(dev(xyz, device), p, *args, False, None, scope='s')
+                    else:
+                        _, feat, _ = U.pointnet_sa_module(dev(xyz, device), p, *args, None, False, False, None, scope='s')
+            finally:
+                U.SA_PRECISION = "fp32"
+            if "init" not in outs:
+                outs["init"] = True
+                st.randomize_batch_norm(7)
+                continue
+            outs[precision] = feat.cpu().numpy()
+        assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
+        err = scaled_err(outs["bf16"], outs["fp32"])
+        assert 1e-6 < err <= BF16_RTOL, (kind, args[0], err)
