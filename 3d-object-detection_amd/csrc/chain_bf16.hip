@@ -152,13 +152,58 @@ __device__ __forceinline__ void layer_t(Out (&out)[NT], const Act (&in)[NJ], con
 }
 
 // max over the wave's points of relu(acc + shift) for the lane's channel, merged into
-// gmax[channel] with an integer atomic max (values >= +0 order like their bit patterns)
-__device__ __forceinline__ void max_points(const floatx16 &acc, float sh, float *gmax)
+// dst[channel] with an integer atomic max (values >= +0 order like their bit patterns).
+// dst: the output row in memory, or the workgroup's LDS copy of it (see WgPool).
+__device__ __forceinline__ void max_points(const floatx16 &acc, float sh, int *dst)
 {
     float m = fmaxf(acc[0], acc[1]);
 #pragma unroll
     for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(acc[r], acc[r + 1]));
-    atomicMax(reinterpret_cast<int *>(gmax), __float_as_int(fmaxf(m + sh, 0.f)));
+    atomicMax(dst, __float_as_int(fmaxf(m + sh, 0.f)));
+}
+
+// Maxima over points leave a wave as one atomic per (32-channel tile, lane); at bf16
+// speed the memory-side atomic units, not the matrix cores, would set the pace (measured:
+// the seg head takes 0.82 ms with, 0.42 ms without them).  So the four waves of a
+// workgroup first merge their maxima in LDS (ds_max, no return value, nothing waits on
+// it) and the workgroup then issues one memory atomic per channel: 8x fewer.  That needs
+// every wave of the workgroup to have rows and the pooling groups (g rows each: a
+// frustum's points, a ball's samples) to tile the workgroup's 128 rows evenly; otherwise
+// the waves update memory directly.
+struct WgPool {
+    bool on;          // workgroup-uniform
+    int groups;       // pooling groups inside this workgroup's rows (1, 2 or 4)
+    int local;        // this wave's group among them
+    long first;       // index of the workgroup's first group
+};
+
+__device__ __forceinline__ WgPool wg_pool(long rows, int g)
+{
+    constexpr int kRows = kWaves * 32;
+    const long r0 = (long)blockIdx.x * kRows;
+    WgPool w;
+    w.on = r0 + kRows <= rows && (g % kRows == 0 || kRows % g == 0);
+    w.groups = g >= kRows ? 1 : kRows / g;
+    w.local = g >= kRows ? 0 : (int)((threadIdx.x >> 6) * 32 / g);
+    w.first = r0 / g;
+    return w;
+}
+
+template <int C>
+__device__ __forceinline__ void wg_pool_clear(int (&lmax)[4 * C], const WgPool &w)
+{
+    for (int i = threadIdx.x; i < w.groups * C; i += 64 * kWaves) lmax[i] = 0;
+    __syncthreads();
+}
+
+// after the last layer: LDS maxima -> memory; out row of group k at out + (first + k) * ld
+template <int C>
+__device__ __forceinline__ void wg_pool_flush(int (&lmax)[4 * C], const WgPool &w, float *out, int ld, int cvalid)
+{
+    __syncthreads();
+    for (int k = 0; k < w.groups; ++k)
+        for (int ch = threadIdx.x; ch < cvalid; ch += 64 * kWaves)
+            atomicMax(reinterpret_cast<int *>(out + (w.first + k) * ld + ch), lmax[k * C + ch]);
 }
 
 // Last layer of a stack: gmax[0 : 32 NT] = max(gmax, max over the 32 points of
@@ -167,7 +212,7 @@ __device__ __forceinline__ void max_points(const floatx16 &acc, float sh, float 
 // padded up to a multiple of 128) are not written.
 template <int NJ, int NT, int R0, int RING>
 __device__ __forceinline__ void layer_max(const Act (&in)[NJ], const bf16x8 *__restrict__ ws,
-                                          const float *__restrict__ sh, float *__restrict__ gmax,
+                                          const float *__restrict__ sh, int *gmax,
                                           WUnit (&ring)[RING], unsigned lane, int cvalid = 32 * NT)
 {
     static_assert(NJ >= 2 && NT % 4 == 0 && (2 * NJ) % RING == 0, "unsupported layer shape");
@@ -262,15 +307,24 @@ struct HeadParams {
     int ldg;
 };
 
-constexpr int kHeadRing = 4;
+#ifndef FPN_BF16_HEAD_RING
+#define FPN_BF16_HEAD_RING 4
+#endif
+constexpr int kHeadRing = FPN_BF16_HEAD_RING;
 
-__global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadParams p)
+#ifndef FPN_BF16_HEAD_WPE
+#define FPN_BF16_HEAD_WPE 1
+#endif
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(FPN_BF16_HEAD_WPE, FPN_BF16_HEAD_WPE))) void seg_head_bf16_kernel(const HeadParams p)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;
-    float *gmax = p.gmax + (row0 / p.n) * p.ldg;
+    __shared__ int lmax[4 * 1024];
+    const WgPool pool = wg_pool(p.rows, p.n);
+    if (!pool.on && row0 >= p.rows) return;
+    if (pool.on) wg_pool_clear<1024>(lmax, pool);
+    int *gmax = reinterpret_cast<int *>(p.gmax + (row0 / p.n) * p.ldg);
 
     WUnit ring[kHeadRing];
     fill_ring(ring, p.ws, lane);
@@ -292,7 +346,12 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
         for (int s = 0; s < 2; ++s) p.point_feat[(row0 + pt) * 8 + (2 * t + s) * 2 + h] = a3[t].m[s];
     layer_t<2, 4, (U2 + U3) % kHeadRing>(a4, a3, ws, p.sh4, ring, lane, h);
     ws += U4 * kUnitVecs;
-    layer_max<4, 32, (U2 + U3 + U4) % kHeadRing>(a4, ws, p.sh5, gmax, ring, lane);
+    if (pool.on) {      // (two copies of the layer: LDS and memory atomics are different instructions)
+        layer_max<4, 32, (U2 + U3 + U4) % kHeadRing>(a4, ws, p.sh5, lmax + pool.local * 1024, ring, lane);
+        wg_pool_flush<1024>(lmax, pool, p.gmax, p.ldg, 1024);
+    } else {
+        layer_max<4, 32, (U2 + U3 + U4) % kHeadRing>(a4, ws, p.sh5, gmax, ring, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -310,7 +369,10 @@ struct TailParams {
     float *logits;                       // (rows,2)
 };
 
-constexpr int kTailRing = 8;
+#ifndef FPN_BF16_TAIL_RING
+#define FPN_BF16_TAIL_RING 8
+#endif
+constexpr int kTailRing = FPN_BF16_TAIL_RING;
 
 __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailParams p)
 {
@@ -372,7 +434,10 @@ struct ObjParams {
     int ldg;
 };
 
-constexpr int kObjRing = 4;
+#ifndef FPN_BF16_OBJ_RING
+#define FPN_BF16_OBJ_RING 4
+#endif
+constexpr int kObjRing = FPN_BF16_OBJ_RING;
 
 template <bool BOX>
 __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjParams p)
@@ -380,9 +445,13 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;
+    constexpr int C = BOX ? 512 : 256;
+    __shared__ int lmax[4 * C];
+    const WgPool pool = wg_pool(p.rows, p.m);
+    if (!pool.on && row0 >= p.rows) return;
+    if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long frustum = row0 / p.m;
-    float *gmax = p.gmax + frustum * p.ldg;
+    int *gmax = reinterpret_cast<int *>(p.gmax + frustum * p.ldg);
 
     WUnit ring[kObjRing];
     fill_ring(ring, p.ws, lane);
@@ -400,13 +469,16 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     layer_t<4, 4, 0>(a2, a1, ws, p.sh2, ring, lane, h);
     ws += U2 * kUnitVecs;
     if constexpr (!BOX) {
-        layer_max<4, 8, U2 % kObjRing>(a2, ws, p.sh3, gmax, ring, lane);
+        if (pool.on) layer_max<4, 8, U2 % kObjRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane);
+        else layer_max<4, 8, U2 % kObjRing>(a2, ws, p.sh3, gmax, ring, lane);
     } else {
         Act a3[8];
         layer_t<4, 8, U2 % kObjRing>(a3, a2, ws, p.sh3, ring, lane, h);
         ws += U3 * kUnitVecs;
-        layer_max<8, 16, (U2 + U3) % kObjRing>(a3, ws, p.sh4, gmax, ring, lane);
+        if (pool.on) layer_max<8, 16, (U2 + U3) % kObjRing>(a3, ws, p.sh4, lmax + pool.local * C, ring, lane);
+        else layer_max<8, 16, (U2 + U3) % kObjRing>(a3, ws, p.sh4, gmax, ring, lane);
     }
+    if (pool.on) wg_pool_flush<C>(lmax, pool, p.gmax, p.ldg, C);
 }
 
 // ---------------------------------------------------------------------------
@@ -436,13 +508,17 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;
+    constexpr int C = 32 * NT3;
+    __shared__ int lmax[4 * C];
+    const WgPool pool = wg_pool(p.rows, p.ns);
+    if (!pool.on && row0 >= p.rows) return;
+    if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long ball = row0 / p.ns;
     const long b = ball / p.m;
     const int pid = p.idx[row0 + pt];
     const float *ctr = p.new_xyz + ball * 3;
     const float *src = p.xyz + (b * p.n + pid) * 3;
-    float *gmax = p.out + ball * p.ldo;
+    int *gmax = reinterpret_cast<int *>(p.out + ball * p.ldo);
 
     WUnit ring[kSaRing];
     fill_ring(ring, p.ws, lane);
@@ -476,7 +552,8 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
         ws += U1 * kUnitVecs;
         layer_t<NT1, NT2, U1 % kSaRing>(a2, a1, ws, p.sh2, ring, lane, h);
         ws += U2 * kUnitVecs;
-        layer_max<NT2, NT3, (U1 + U2) % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+        if (pool.on) layer_max<NT2, NT3, (U1 + U2) % kSaRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
+        else layer_max<NT2, NT3, (U1 + U2) % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
     } else {
         float x[4];
 #pragma unroll
@@ -491,8 +568,10 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
         constexpr int U2 = (NT2 / 2) * NT1;
         layer_t<NT1, NT2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
         ws += U2 * kUnitVecs;
-        layer_max<NT2, NT3, U2 % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+        if (pool.on) layer_max<NT2, NT3, U2 % kSaRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
+        else layer_max<NT2, NT3, U2 % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
     }
+    if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
 }
 
 // w (cin,cout) fp32 row-major, scale (cout) or NULL -> the layer's units:

@@ -423,7 +423,7 @@ __device__ __forceinline__ void mfma_pair_n(floatx16 &acc_a, floatx16 &acc_b, co
 // max over the wave's 32 points of relu(acc * sc + sh) for the lane's channel, merged
 // into gmax[channel] with an integer atomic max: the values are >= +0, and for those
 // the order of the bit patterns is the order of the floats.
-__device__ __forceinline__ void max_points(const floatx16 &acc, float sc, float sh, float *gmax, int h)
+__device__ __forceinline__ void max_points(const floatx16 &acc, float sc, float sh, int *gmax, int h)
 {
     float m = 0.f;
     const floatx2 s2 = {sc, sc}, b2 = {sh, sh};
@@ -438,7 +438,49 @@ __device__ __forceinline__ void max_points(const floatx16 &acc, float sc, float 
     // whose wait stalls the MFMA stream, and a branch on the half would split the double
     // step into several scheduling regions.
     (void)h;
-    atomicMax(reinterpret_cast<int *>(gmax), __float_as_int(m));
+    atomicMax(gmax, __float_as_int(m));
+}
+
+// The four waves of a workgroup can merge their maxima in LDS first (ds_max without a
+// return value: nothing waits on it) and then issue one memory atomic per channel for
+// the whole workgroup, 8x fewer than one per wave and lane half.  That needs every wave
+// of the workgroup to have rows, and the pooling groups (g rows each: a frustum's
+// points, a ball's samples) to tile the workgroup's 128 rows evenly; otherwise the waves
+// update memory directly.
+struct WgPool {
+    bool on;          // workgroup-uniform
+    int groups;       // pooling groups inside this workgroup's rows (1, 2 or 4)
+    int local;        // this wave's group among them
+    long first;       // index of the workgroup's first group
+};
+
+__device__ __forceinline__ WgPool wg_pool(long rows, int g)
+{
+    constexpr int kRows = kRegWaves * 32;
+    const long r0 = (long)blockIdx.x * kRows;
+    WgPool w;
+    w.on = r0 + kRows <= rows && (g % kRows == 0 || kRows % g == 0);
+    w.groups = g >= kRows ? 1 : kRows / g;
+    w.local = g >= kRows ? 0 : (int)((threadIdx.x >> 6) * 32 / g);
+    w.first = r0 / g;
+    return w;
+}
+
+template <int C>
+__device__ __forceinline__ void wg_pool_clear(int (&lmax)[4 * C], const WgPool &w)
+{
+    for (int i = threadIdx.x; i < w.groups * C; i += 64 * kRegWaves) lmax[i] = 0;
+    __syncthreads();
+}
+
+// after the last layer: LDS maxima -> memory; the row of group k is out + (first + k) * ld
+template <int C>
+__device__ __forceinline__ void wg_pool_flush(int (&lmax)[4 * C], const WgPool &w, float *out, int ld, int cvalid)
+{
+    __syncthreads();
+    for (int k = 0; k < w.groups; ++k)
+        for (int ch = threadIdx.x; ch < cvalid; ch += 64 * kRegWaves)
+            atomicMax(reinterpret_cast<int *>(out + (w.first + k) * ld + ch), lmax[k * C + ch]);
 }
 
 // Last layer of a stack: gmax[0:32 NT] = max(gmax, max over the 32 points of
@@ -449,7 +491,7 @@ __device__ __forceinline__ void max_points(const floatx16 &acc, float sc, float 
 template <int NJ, int NT, int P0 = 0>
 __device__ __forceinline__ void layer_max(const floatx16 (&in)[NJ], const float4 *__restrict__ w,
                                           const float *__restrict__ sc, const float *__restrict__ sh,
-                                          float *__restrict__ gmax, WChunk (&ring)[4], unsigned lane, int h,
+                                          int *gmax, WChunk (&ring)[4], unsigned lane, int h,
                                           int cvalid = 32 * NT)
 {
     static_assert(NJ >= 2 && NJ % 2 == 0 && NT % 4 == 0, "unsupported layer shape");
@@ -555,8 +597,11 @@ __global__ __launch_bounds__(64 * kHeadWaves) void seg_head_reg_kernel(const Seg
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)blockIdx.x * kHeadWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;
-    float *gmax = p.gmax + (row0 / p.n) * p.ldg;
+    __shared__ int lmax[4 * 1024];
+    const WgPool pool = wg_pool(p.rows, p.n);
+    if (!pool.on && row0 >= p.rows) return;
+    if (pool.on) wg_pool_clear<1024>(lmax, pool);
+    int *gmax = reinterpret_cast<int *>(p.gmax + (row0 / p.n) * p.ldg);
     FPN_STAMP(0);
 
     WChunk ring[4];
@@ -585,7 +630,12 @@ __global__ __launch_bounds__(64 * kHeadWaves) void seg_head_reg_kernel(const Seg
     FPN_STAMP(3);
     layer_t<2, 4>(a4, a3, p.w4, p.sc4, p.sh4, ring, p.w5, p.w5 + 4 * 256, lane, h);
     FPN_STAMP(4);
-    layer_max<4, 32>(a4, p.w5, p.sc5, p.sh5, gmax, ring, lane, h);
+    if (pool.on) {     // two copies of the layer: LDS and memory atomics are different instructions
+        layer_max<4, 32>(a4, p.w5, p.sc5, p.sh5, lmax + pool.local * 1024, ring, lane, h);
+        wg_pool_flush<1024>(lmax, pool, p.gmax, p.ldg, 1024);
+    } else {
+        layer_max<4, 32>(a4, p.w5, p.sc5, p.sh5, gmax, ring, lane, h);
+    }
     FPN_STAMP(5);
 }
 
@@ -611,9 +661,13 @@ __global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const Obj
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;
+    constexpr int C = BOX ? 512 : 256;
+    __shared__ int lmax[4 * C];
+    const WgPool pool = wg_pool(p.rows, p.m);
+    if (!pool.on && row0 >= p.rows) return;
+    if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long frustum = row0 / p.m;
-    float *gmax = p.gmax + frustum * p.ldg;
+    int *gmax = reinterpret_cast<int *>(p.gmax + frustum * p.ldg);
 
     WChunk ring[4];
     load_chunk(ring[0], p.w2, lane);                 // layer 2 chunks (0,0), (1,0)
@@ -631,12 +685,15 @@ __global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const Obj
     layer_first<4, 2>(a1, x, p.w1, 3, p.sc1, p.sh1, lane, h);
     layer_t<4, 4>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + 4 * 256, lane, h);
     if constexpr (!BOX) {
-        layer_max<4, 8>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h);
+        if (pool.on) layer_max<4, 8>(a2, p.w3, p.sc3, p.sh3, lmax + pool.local * C, ring, lane, h);
+        else layer_max<4, 8>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h);
     } else {
         floatx16 a3[8];
         layer_t<4, 8>(a3, a2, p.w3, p.sc3, p.sh3, ring, p.w4, p.w4 + 8 * 256, lane, h);
-        layer_max<8, 16>(a3, p.w4, p.sc4, p.sh4, gmax, ring, lane, h);
+        if (pool.on) layer_max<8, 16>(a3, p.w4, p.sc4, p.sh4, lmax + pool.local * C, ring, lane, h);
+        else layer_max<8, 16>(a3, p.w4, p.sc4, p.sh4, gmax, ring, lane, h);
     }
+    if (pool.on) wg_pool_flush<C>(lmax, pool, p.gmax, p.ldg, C);
 }
 
 // ---------------------------------------------------------------------------
@@ -671,13 +728,17 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;
+    constexpr int C = 32 * NT3;
+    __shared__ int lmax[4 * C];
+    const WgPool pool = wg_pool(p.rows, p.ns);
+    if (!pool.on && row0 >= p.rows) return;
+    if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long ball = row0 / p.ns;                    // = b * m + j
     const long b = ball / p.m;
     const int pid = p.idx[row0 + pt];                 // this lane's neighbour
     const float *ctr = p.new_xyz + ball * 3;
     const float *src = p.xyz + (b * p.n + pid) * 3;
-    float *gmax = p.out + ball * p.ldo;
+    int *gmax = reinterpret_cast<int *>(p.out + ball * p.ldo);
 
     WChunk ring[4];
     constexpr int NJ1 = NJF > 0 ? NJF + 1 : 2;       // input tiles of layer 1 (unused when NJF = 0)
@@ -705,7 +766,8 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
         constexpr int P1 = ((NT1 / 2) * NJ1) & 1;
         layer_t<NT1, NT2, P1>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
         constexpr int P2 = (P1 + (NT2 / 2) * NT1) & 1;
-        layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
+        if (pool.on) layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, lmax + pool.local * C, ring, lane, h, p.c3);
+        else layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
     } else {
         load_chunk(ring[0], p.w2, lane);
         load_chunk(ring[1], p.w2 + (size_t)NT1 * 256, lane);
@@ -722,8 +784,10 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
         layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
         layer_t<NT1, NT2, 0>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
         constexpr int P2 = ((NT2 / 2) * NT1) & 1;
-        layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
+        if (pool.on) layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, lmax + pool.local * C, ring, lane, h, p.c3);
+        else layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
     }
+    if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
 }
 
 // w (cin,cout) row-major -> 4 KiB chunks for the register chains, one per

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 16x the fp32 rate (v_mfma_f32_32x32x16_bf16, 32 cycles / 16384 MAC)
 ALGO_GFLOP_PER_FRUSTUM = None   # filled from the layer table below
 
 
@@ -200,6 +201,9 @@ def side_config(args):
         pc_np, oh_np = synthetic.make_frustums(b_local, points, 4, seed=rank)
         pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
         st = variables.VariableStore(dev, seed=1)
+        if args.dtype == "bf16":
+            from fpn import pointnet_util
+            pointnet_util.SA_PRECISION = "bf16"       # the fused set-abstraction kernels
         with variables.use_store(st):
             M2.get_model(pc[:2], one_hot[:2], False)      # creates the variables
         st.randomize_batch_norm(2)
@@ -208,7 +212,8 @@ def side_config(args):
             with variables.use_store(st):
                 return fdist.pack_results(M2.get_model(pc, one_hot, False))
         label = "Frustum PointNet v2 (SA-MSG x2, SA, FP x3; box net SA x3) inference, %d frustums x %d pts x 4 ch " \
-                "per GPU, fp32" % (b_local, points)
+                "per GPU, %s" % (b_local, points, "bf16 MFMA in the set-abstraction kernels, fp32 elsewhere"
+                                 if args.dtype == "bf16" else "fp32")
         metric = "frustums/sec (node) FPointNet v2 N=%d" % points
     else:
         from fpn import bayes, uncertainty
@@ -267,7 +272,9 @@ def side_config(args):
         print(json.dumps({"metric": metric, "value": world * b_local * args.steps / dt, "unit": "frustums/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "vs_baseline": None,
+                          "dtype": "bf16" if (args.dtype == "bf16" and args.config == "v2") else "f32",
+                          "data": "synthetic",
                           "config": {"workload": label, "frustums_per_gpu": b_local, "points": points}}))
     if world > 1:
         dist.destroy_process_group()
@@ -288,6 +295,9 @@ def main():
                     help="v1: BASELINE config 1 (the headline metric, default); v2: PointNet++ variant, 2048 points "
                          "(config 2); bayes: Flipout v1 with --samples Monte-Carlo passes per frustum (config 3)")
     ap.add_argument("--samples", type=int, default=32, help="Monte-Carlo samples per frustum (--config bayes)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="operand type of the layer-chain kernels' matrix products (accumulation is always fp32); "
+                         "f32 is the headline configuration")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a HIP graph (side configs; removes the host launch overhead)")
     args = ap.parse_args()
@@ -308,7 +318,9 @@ def main():
     st = variables.VariableStore(dev, seed=1)
     plan.init_variables(st, 4, True)
     st.randomize_batch_norm(2)
-    net = plan.V1Plan(st, 4, True, chunk_frustums=args.chunk or None)
+    bf16 = args.dtype == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    net = plan.V1Plan(st, 4, True, chunk_frustums=args.chunk or None, precision="bf16" if bf16 else "fp32")
     b_local = args.batch
     pc_np, oh_np = synthetic.make_frustums(b_local, args.points, 4, seed=rank)
     pc = torch.from_numpy(pc_np).to(dev)
@@ -353,13 +365,14 @@ def main():
         "metric": "frustums/sec (node) FPointNet v1 N=%d" % args.points,
         "value": value, "unit": "frustums/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Frustum PointNet v1 inference, %d frustums x %d pts x 4 ch per GPU, fp32 MFMA "
-                               "(BASELINE config 1)" % (b_local, args.points),
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "Frustum PointNet v1 inference, %d frustums x %d pts x 4 ch per GPU, %s"
+                               % (b_local, args.points, "bf16 MFMA with fp32 accumulation (not the headline "
+                                  "configuration, which is fp32)" if bf16 else "fp32 MFMA (BASELINE config 1)"),
                    "frustums_per_gpu": b_local, "points": args.points,
                    "algorithmic_gflop_per_frustum": 2 * macs / 1e9,
                    "model_tflops": value * 2 * macs / 1e12,
-                   "model_frac_of_fp32_mfma_peak": value * 2 * macs / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+                   "model_frac_of_mfma_peak": value * 2 * macs / 1e12 / (peak * world),
                    "parallelism": "frustum-sharded x%d, all_gather of %d-float records" % (world, fdist.RECORD)},
     }
     if rank == 0:
@@ -369,8 +382,8 @@ def main():
             launches, flops, secs = agg[name]
             ach = flops / secs / 1e12
             traffic, traffic_src = measured_traffic(name, b_local, args.points) if not args.chunk else (None, None)
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": traffic,
                                "traffic_source": traffic_src, "kernel": name,
                                "launches": launches, "avg_launch_ms": secs / launches * 1e3,
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,

@@ -62,7 +62,11 @@ def test_bf16_chains_exact_on_integer_data(device):
     f32 = plan.V1Plan(st, 4, False)
     b16 = plan.V1Plan(st, 4, False, precision="bf16")
     rng = np.random.RandomState(0)
-    for b_, n in ((3, 256), (2, 1024), (5, 96)):
+    # 256, 1024: a workgroup's 128 rows lie in one frustum (maxima merged in LDS first);
+    # 64, 32: two / four frustums per workgroup; 96: frustum boundaries inside a workgroup
+    # and a last workgroup with idle waves (direct memory atomics); 7 x 32: a partial last
+    # workgroup next to full ones
+    for b_, n in ((3, 256), (2, 1024), (5, 96), (4, 64), (8, 32), (7, 32)):
         pc = rng.randint(0, 8, (b_, n, 4)).astype(np.float32)
         one_hot = np.eye(3, dtype=np.float32)[rng.randint(0, 3, b_)]
         a = f32.forward(dev(pc, device), dev(one_hot, device))
