@@ -109,3 +109,9 @@ def get_center_regression_net(object_point_cloud, one_hot_vec, is_training, bn_d
                                   bn_decay=bn_decay)
     predicted_center = tf_util.fully_connected(net, 3, activation_fn=None, scope='fc3-stage1')
     return predicted_center, end_points
+
+
+# Record parsing (models/model_util.py:89-144) lives in fpn.frustum_records; the
+# reference's names stay importable from here.
+from .frustum_records import (parse_data, parse_frustum_point_record,  # noqa: E402,F401
+                              parse_frustum_point_test_record, parse_test_data)

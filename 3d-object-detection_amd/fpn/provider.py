@@ -5,11 +5,18 @@ class2angle :73, size2class :85, class2size :101, get_3d_box :282,
 from_prediction_to_label_format :366).  Host-side numpy, per-box scalar work exactly
 as in the reference; every function also accepts arrays and then works element-wise.
 
-Not provided: FrustumDataset (:107, a Keras Sequence over pickled KITTI frustums) and
-compute_box3d_iou (:313), which calls a `box3d_iou` whose import the reference has
-commented out (:20) and therefore cannot run there either; box overlaps are in
-helpers.mAP_evaluation.
+FrustumDataset (:107-275) reads the pickled frustum lists of the extraction step and
+returns resampled, centre-rotated frustums with their labels; it draws from numpy's
+global generator in the reference's order (resampling choice, flip, shift), so the same
+np.random.seed gives the same samples.
+
+Not provided: compute_box3d_iou (:313), which calls a `box3d_iou` whose import the
+reference has commented out (:20) and therefore cannot run there either; box overlaps
+are in helpers.mAP_evaluation.
 """
+import io
+import pickle
+
 import numpy as np
 
 from .model_util import (NUM_HEADING_BIN, NUM_SIZE_CLUSTER, g_class2type, g_type2class,  # noqa: F401
@@ -73,6 +80,125 @@ def get_3d_box(box_size, heading_angle, center):
     corners[1, :] = corners[1, :] + center[1]
     corners[2, :] = corners[2, :] + center[2]
     return np.transpose(corners)
+
+
+class _ListUnpickler(pickle.Unpickler):
+    """The frustum files hold lists of strings, numbers and numpy arrays; nothing else is
+    allowed to be constructed while reading them."""
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.numeric", "_frombuffer"),
+                ("numpy._core.numeric", "_frombuffer")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("frustum file refers to %s.%s: only lists of strings, numbers and numpy "
+                                     "arrays are accepted" % (module, name))
+
+
+def load_frustum_lists(path, count):
+    """The `count` consecutive pickled lists of a frustum file (latin1, as the reference
+    opens the Python-2 era files, :143-162)."""
+    with open(path, "rb") as fp:
+        data = fp.read()
+    buf = io.BytesIO(data)
+    return [_ListUnpickler(buf, encoding="latin1").load() for _ in range(count)]
+
+
+class FrustumDataset(object):
+    """scripts/provider.py:107-275.  Items: with from_rgb_detection (point_set, rot_angle,
+    prob[, one_hot_vec]); otherwise (point_set, seg, box3d_center, angle_class,
+    angle_residual, size_class, size_residual, rot_angle[, one_hot_vec]).
+    `lists`, if given, supplies the frustum lists directly instead of a pickle file."""
+
+    def __init__(self, npoints, split, batch_size=32, random_flip=False, random_shift=False, rotate_to_center=False,
+                 overwritten_data_path=None, from_rgb_detection=False, one_hot=False, lists=None):
+        self.npoints = npoints
+        self.batch_size = batch_size
+        self.random_flip = random_flip
+        self.random_shift = random_shift
+        self.rotate_to_center = rotate_to_center
+        self.one_hot = one_hot
+        self.from_rgb_detection = from_rgb_detection
+        if lists is None:
+            if overwritten_data_path is None:
+                raise ValueError("no frustum file: pass overwritten_data_path (the reference's default, "
+                                 "kitti/frustum_carpedcyc_%s.pickle next to its sources, does not exist here)" % split)
+            lists = load_frustum_lists(overwritten_data_path, 6 if from_rgb_detection else 9)
+        if from_rgb_detection:
+            (self.id_list, self.box2d_list, self.input_list, self.type_list, self.frustum_angle_list,
+             self.prob_list) = lists
+        else:
+            (self.id_list, self.box2d_list, self.box3d_list, self.input_list, self.label_list, self.type_list,
+             self.heading_list, self.size_list, self.frustum_angle_list) = lists
+
+    def __len__(self):
+        return len(self.input_list)
+
+    def get_center_view_rot_angle(self, index):
+        """Frustum angle shifted by pi/2 so that it also corrects the heading (:242-245)."""
+        return np.pi / 2.0 + self.frustum_angle_list[index]
+
+    def get_box3d_center(self, index):
+        return (self.box3d_list[index][0, :] + self.box3d_list[index][6, :]) / 2.0
+
+    def get_center_view_box3d_center(self, index):
+        c = (self.box3d_list[index][0, :] + self.box3d_list[index][6, :]) / 2.0
+        return rotate_pc_along_y(np.expand_dims(c, 0), self.get_center_view_rot_angle(index)).squeeze()
+
+    def get_center_view_box3d(self, index):
+        return rotate_pc_along_y(np.copy(self.box3d_list[index]), self.get_center_view_rot_angle(index))
+
+    def get_center_view_point_set(self, index):
+        return rotate_pc_along_y(np.copy(self.input_list[index]), self.get_center_view_rot_angle(index))
+
+    def __getitem__(self, index):
+        rot_angle = self.get_center_view_rot_angle(index)
+        if self.one_hot:
+            cls_type = self.type_list[index]
+            assert cls_type in g_type2onehotclass, cls_type
+            one_hot_vec = np.zeros(3)
+            one_hot_vec[g_type2onehotclass[cls_type]] = 1
+        point_set = self.get_center_view_point_set(index) if self.rotate_to_center else self.input_list[index]
+        # resample to npoints: with replacement only when there are too few (:186-191)
+        n = point_set.shape[0]
+        choice = np.random.choice(n, self.npoints, replace=n < self.npoints)
+        point_set = point_set[choice, :]
+        if self.from_rgb_detection:
+            if self.one_hot:
+                return point_set, rot_angle, self.prob_list[index], one_hot_vec
+            return point_set, rot_angle, self.prob_list[index]
+        seg = self.label_list[index][choice]
+        box3d_center = self.get_center_view_box3d_center(index) if self.rotate_to_center else self.get_box3d_center(index)
+        heading_angle = self.heading_list[index] - rot_angle if self.rotate_to_center else self.heading_list[index]
+        size_class, size_residual = size2class(self.size_list[index], self.type_list[index])
+        if self.random_flip and np.random.random() > 0.5:       # :219-225
+            point_set[:, 0] *= -1
+            box3d_center[0] *= -1
+            heading_angle = np.pi - heading_angle
+        if self.random_shift:                                     # :226-230, the reference's formula as written
+            dist = np.sqrt(np.sum(box3d_center[0] ** 2 + box3d_center[1] ** 2))
+            shift = np.clip(np.random.randn() * dist * 0.05, dist * 0.8, dist * 1.2)
+            point_set[:, 2] += shift
+            box3d_center[2] += shift
+        angle_class, angle_residual = angle2class(heading_angle, NUM_HEADING_BIN)
+        if self.one_hot:
+            return (point_set, seg, box3d_center, angle_class, angle_residual, size_class, size_residual, rot_angle,
+                    one_hot_vec)
+        return point_set, seg, box3d_center, angle_class, angle_residual, size_class, size_residual, rot_angle
+
+    def batch(self, indices, device, channels=None):
+        """Items `indices` as get_model inputs: point_cloud (B,npoints,C) float32 and, with
+        one_hot, one_hot (B,3) float32 on `device`, plus the list of the items' other
+        fields."""
+        import torch
+        items = [self[i] for i in indices]
+        pc = np.stack([it[0][:, :channels] for it in items]).astype(np.float32)
+        out = [torch.from_numpy(pc).to(device)]
+        if self.one_hot:
+            out.append(torch.from_numpy(np.stack([it[-1] for it in items]).astype(np.float32)).to(device))
+        return tuple(out) + ([it[1:] for it in items],)
 
 
 def from_prediction_to_label_format(center, angle_class, angle_res, size_class, size_res, rot_angle):
