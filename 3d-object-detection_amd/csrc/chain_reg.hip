@@ -156,6 +156,24 @@ __device__ __forceinline__ void mfma_pair(floatx16 &acc_a, floatx16 &acc_b, cons
     }
 }
 
+// Flipout: each frustum has its own effective weights (fpn_flipout_weights_f32), so
+// the weight stream of a wave is its frustum's copy.  The workgroups of one frustum are
+// then placed on ONE XCD (consecutive workgroup ids go round the eight XCDs, so id i
+// handles logical block (i % 8) * (grid / 8) + i / 8): its 0.2 - 0.9 MB of weights are
+// read by all its waves out of that XCD's L2 instead of out of all eight.
+__device__ __forceinline__ unsigned logical_block(int per_frustum)
+{
+    const unsigned g = gridDim.x, i = blockIdx.x;
+    return (per_frustum && g % 8 == 0) ? (i % 8) * (g / 8) + i / 8 : i;
+}
+
+// the wave's frustum as a scalar (the wave index comes from threadIdx and would
+// otherwise make every weight address a vector computation)
+__device__ __forceinline__ size_t scalar_index(long v)
+{
+    return (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 struct SegTailRegParams {
     long rows;
     int n;
@@ -171,6 +189,7 @@ struct SegTailRegParams {
     const float *sc9, *sh9;
     const float *w10, *b10;       // (128,2) row-major, (2)
     float *logits;                // (rows,2)
+    int per_frustum;              // every weight array holds one copy per frustum (Flipout)
 };
 
 // The loop body of conv6-chunk kc / conv7-partial kc is 20 double steps; double step D
@@ -192,13 +211,22 @@ __device__ __forceinline__ const float4 *tail_body_chunk(const SegTailRegParams 
     }
 }
 
-__global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegTailRegParams p)
+__global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegTailRegParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;   // waves are independent (no barriers): a surplus wave just leaves
-    const long frustum = row0 / p.n;
+    const long row0 = ((long)logical_block(pin.per_frustum) * kRegWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= pin.rows) return;   // waves are independent (no barriers): a surplus wave just leaves
+    const long frustum = row0 / pin.n;
+    SegTailRegParams p = pin;
+    if (pin.per_frustum) {
+        const size_t f = scalar_index(frustum);
+        p.w6 += f * (64 * 512 / 4);
+        p.w7 += f * (512 * 256 / 4);
+        p.w8 += f * (256 * 128 / 4);
+        p.w9 += f * (128 * 128 / 4);
+        p.w10 += f * (128 * 2);
+    }
     const float *gs = p.gshift + frustum * 512;
     FPN_STAMP(0);
 
@@ -454,10 +482,10 @@ struct WgPool {
     long first;       // index of the workgroup's first group
 };
 
-__device__ __forceinline__ WgPool wg_pool(long rows, int g)
+__device__ __forceinline__ WgPool wg_pool(long rows, int g, unsigned block)
 {
     constexpr int kRows = kRegWaves * 32;
-    const long r0 = (long)blockIdx.x * kRows;
+    const long r0 = (long)block * kRows;
     WgPool w;
     w.on = r0 + kRows <= rows && (g % kRows == 0 || kRows % g == 0);
     w.groups = g >= kRows ? 1 : kRows / g;
@@ -585,6 +613,7 @@ struct SegHeadRegParams {
     float *point_feat;                     // (rows,64)
     float *gmax;                           // (rows/n, ldg): running maximum of conv5's output
     int ldg;
+    int per_frustum;                       // every weight array holds one copy per frustum (Flipout)
 };
 
 // The head needs few enough registers for two waves per SIMD (two workgroups per CU).
@@ -592,14 +621,24 @@ struct SegHeadRegParams {
 // measured slower (2.48 vs 2.36 ms): the two waves then also stall together.
 constexpr int kHeadWaves = kRegWaves;
 
-__global__ __launch_bounds__(64 * kHeadWaves) void seg_head_reg_kernel(const SegHeadRegParams p)
+__global__ __launch_bounds__(64 * kHeadWaves) void seg_head_reg_kernel(const SegHeadRegParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kHeadWaves + (threadIdx.x >> 6)) * 32;
+    const unsigned block = logical_block(pin.per_frustum);
+    const long row0 = ((long)block * kHeadWaves + (threadIdx.x >> 6)) * 32;
     __shared__ int lmax[4 * 1024];
-    const WgPool pool = wg_pool(p.rows, p.n);
-    if (!pool.on && row0 >= p.rows) return;
+    const WgPool pool = wg_pool(pin.rows, pin.n, block);
+    if (!pool.on && row0 >= pin.rows) return;
+    SegHeadRegParams p = pin;
+    if (pin.per_frustum) {
+        const size_t f = scalar_index(row0 / pin.n);
+        p.w1 += f * (size_t)(pin.cpc * 64);
+        p.w2 += f * (64 * 64 / 4);
+        p.w3 += f * (64 * 64 / 4);
+        p.w4 += f * (64 * 128 / 4);
+        p.w5 += f * (128 * 1024 / 4);
+    }
     if (pool.on) wg_pool_clear<1024>(lmax, pool);
     int *gmax = reinterpret_cast<int *>(p.gmax + (row0 / p.n) * p.ldg);
     FPN_STAMP(0);
@@ -653,18 +692,28 @@ struct ObjChainRegParams {
     const float4 *w4; const float *sc4, *sh4;   // box net only
     float *gmax;                                // (rows/m, ldg)
     int ldg;
+    int per_frustum;                            // every weight array holds one copy per frustum (Flipout)
 };
 
 template <bool BOX>
-__global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const ObjChainRegParams p)
+__global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const ObjChainRegParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    const unsigned block = logical_block(pin.per_frustum);
+    const long row0 = ((long)block * kRegWaves + (threadIdx.x >> 6)) * 32;
     constexpr int C = BOX ? 512 : 256;
     __shared__ int lmax[4 * C];
-    const WgPool pool = wg_pool(p.rows, p.m);
-    if (!pool.on && row0 >= p.rows) return;
+    const WgPool pool = wg_pool(pin.rows, pin.m, block);
+    if (!pool.on && row0 >= pin.rows) return;
+    ObjChainRegParams p = pin;
+    if (pin.per_frustum) {
+        const size_t f = scalar_index(row0 / pin.m);
+        p.w1 += f * (3 * 128);
+        p.w2 += f * (128 * 128 / 4);
+        p.w3 += f * (128 * 256 / 4);
+        if (BOX) p.w4 += f * (256 * 512 / 4);
+    }
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long frustum = row0 / p.m;
     int *gmax = reinterpret_cast<int *>(p.gmax + frustum * p.ldg);
@@ -730,7 +779,7 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
     const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
     constexpr int C = 32 * NT3;
     __shared__ int lmax[4 * C];
-    const WgPool pool = wg_pool(p.rows, p.ns);
+    const WgPool pool = wg_pool(p.rows, p.ns, blockIdx.x);
     if (!pool.on && row0 >= p.rows) return;
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long ball = row0 / p.ns;                    // = b * m + j
@@ -808,6 +857,35 @@ __global__ void tile_weights_reg_kernel(int cin, int cout, int jmajor, const flo
     }
 }
 
+// Flipout's effective weights, one copy per frustum, written in the layout a chain
+// kernel reads: out[f][e] = wm[k][c] + dw[k][c] * sin[f][k] * sout[f][c] with (k, c) the
+// matrix element that lives at position e of `layout` (0 row-major, 1 / 2 the chunked
+// layout of tile_weights_reg_kernel, output-tile / input-tile major).
+__global__ void flipout_weights_kernel(int cin, int cout, int layout, const float *__restrict__ wm,
+                                       const float *__restrict__ dw, const float *__restrict__ sin, int ldi,
+                                       const float *__restrict__ sout, int ldo, float *__restrict__ out,
+                                       int per_delta, long delta_stride)
+{
+    const long total = (long)cin * cout;
+    const long f = blockIdx.y;
+    dw += (f / per_delta) * delta_stride;      // the Monte-Carlo sample this frustum copy belongs to
+    const int nj = cin / 32, nt = cout / 32;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int k, col;
+        if (layout == 0) {
+            k = (int)(e / cout); col = (int)(e % cout);
+        } else {
+            const int i = e & 3, l = (e >> 2) & 63, q = (e >> 8) & 3;
+            const long chunk = e >> 10;
+            const int t = layout == 2 ? (int)(chunk % nt) : (int)(chunk / nj);
+            const int j = layout == 2 ? (int)(chunk / nt) : (int)(chunk % nj);
+            k = 32 * j + 8 * q + 4 * (l >> 5) + i; col = 32 * t + (l & 31);
+        }
+        const long src = (long)k * cout + col;
+        out[f * total + e] = wm[src] + dw[src] * (sin[f * ldi + k] * sout[f * ldo + col]);
+    }
+}
+
 template <int NJF, int NT1, int NT2, int NT3>
 int launch_sa_chain(const SaChainParams &p, hipStream_t st)
 {
@@ -835,8 +913,29 @@ int fpn_tile_weights_reg_f32(int cin, int cout, int jmajor, const float *w, floa
     return check_launch("fpn_tile_weights_reg_f32");
 }
 
+int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const float *w_delta,
+                            int frustums_per_delta, long delta_stride, const float *sign_in, int ld_in,
+                            const float *sign_out, int ld_out, int layout, float *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && cin >= 1 && cout >= 1, "flipout_weights: bad size");
+    FPN_REQUIRE(frustums_per_delta >= 1 && delta_stride >= 0, "flipout_weights: bad delta grouping %d / stride %ld",
+                frustums_per_delta, delta_stride);
+    FPN_REQUIRE(layout >= 0 && layout <= 2, "flipout_weights: layout %d (0 row-major, 1 chunked, 2 chunked input-tile major)", layout);
+    FPN_REQUIRE(layout == 0 || (cin % 32 == 0 && cout % 32 == 0),
+                "flipout_weights: the chunked layouts need cin (%d) and cout (%d) to be multiples of 32", cin, cout);
+    FPN_REQUIRE(ld_in >= cin && ld_out >= cout, "flipout_weights: leading dimensions %d, %d too small", ld_in, ld_out);
+    if (b == 0) return FPN_OK;
+    FPN_REQUIRE(b <= 65535, "flipout_weights: at most 65535 frustums per call (%d)", b);
+    FPN_REQUIRE(w_mean && w_delta && sign_in && sign_out && out, "flipout_weights: null pointer");
+    const long total = (long)cin * cout;
+    hipLaunchKernelGGL(flipout_weights_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1024), (unsigned)b), dim3(256),
+                       0, as_stream(stream), cin, cout, layout, w_mean, w_delta, sign_in, ld_in, sign_out, ld_out, out,
+                       frustums_per_delta, delta_stride);
+    return check_launch("fpn_flipout_weights_f32");
+}
+
 int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_shift,
-                        const float *const *layers, float *logits, void *stream)
+                        const float *const *layers, int per_frustum, float *logits, void *stream)
 {
     FPN_REQUIRE(rows >= 0 && n >= 1, "v1_seg_tail: bad size");
     FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_tail: points per frustum (%d) must be a multiple of 32", n);
@@ -850,7 +949,7 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
     p.w8 = reinterpret_cast<const float4 *>(layers[5]); p.sc8 = layers[6]; p.sh8 = layers[7];
     p.w9 = reinterpret_cast<const float4 *>(layers[8]); p.sc9 = layers[9]; p.sh9 = layers[10];
     p.w10 = layers[11]; p.b10 = layers[12];
-    p.logits = logits;
+    p.logits = logits; p.per_frustum = per_frustum != 0;
     const long waves = rows / 32;
     hipLaunchKernelGGL(seg_tail_reg_kernel, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
                        as_stream(stream), p);
@@ -896,7 +995,7 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
 }
 
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,
-                        float *point_feat, float *global_max, int ldg, void *stream)
+                        int per_frustum, float *point_feat, float *global_max, int ldg, void *stream)
 {
     FPN_REQUIRE(rows >= 0 && n >= 1 && cpc >= 3 && cpc <= 8, "v1_seg_head: bad size rows=%ld n=%d cpc=%d", rows, n, cpc);
     FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_head: points per frustum (%d) must be a multiple of 32", n);
@@ -911,7 +1010,7 @@ int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float 
     p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
     p.w4 = reinterpret_cast<const float4 *>(layers[9]); p.sc4 = layers[10]; p.sh4 = layers[11];
     p.w5 = reinterpret_cast<const float4 *>(layers[12]); p.sc5 = layers[13]; p.sh5 = layers[14];
-    p.point_feat = point_feat; p.gmax = global_max; p.ldg = ldg;
+    p.point_feat = point_feat; p.gmax = global_max; p.ldg = ldg; p.per_frustum = per_frustum != 0;
     const long waves = rows / 32;
     hipLaunchKernelGGL(seg_head_reg_kernel, dim3((unsigned)((waves + kHeadWaves - 1) / kHeadWaves)), dim3(64 * kHeadWaves), 0,
                        as_stream(stream), p);
@@ -919,7 +1018,7 @@ int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float 
 }
 
 int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
-                         const float *const *layers, float *feat_max, int ldg, void *stream)
+                         const float *const *layers, int per_frustum, float *feat_max, int ldg, void *stream)
 {
     FPN_REQUIRE(rows >= 0 && m >= 1, "v1_obj_chain: bad size");
     FPN_REQUIRE(m % 32 == 0 && rows % m == 0, "v1_obj_chain: object points per frustum (%d) must be a multiple of 32", m);
@@ -934,7 +1033,7 @@ int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const floa
     p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
     p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
     if (box) { p.w4 = reinterpret_cast<const float4 *>(layers[9]); p.sc4 = layers[10]; p.sh4 = layers[11]; }
-    p.gmax = feat_max; p.ldg = ldg;
+    p.gmax = feat_max; p.ldg = ldg; p.per_frustum = per_frustum != 0;
     const long waves = rows / 32;
     const dim3 grid((unsigned)((waves + kRegWaves - 1) / kRegWaves));
     if (box) hipLaunchKernelGGL(obj_chain_reg_kernel<true>, grid, dim3(64 * kRegWaves), 0, as_stream(stream), p);

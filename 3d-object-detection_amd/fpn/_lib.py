@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfpn_hip.so")
 
 FPN_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FpnError(RuntimeError):
@@ -48,9 +48,10 @@ SIGNATURES = {
     "fpn_tile_weights_reg_f32": [_i, _i, _i, _vp, _vp, _vp],
     "fpn_sa_chain_supported": [_i, _i, _i, _i],
     "fpn_sa_chain_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
-    "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
-    "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
+    "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "fpn_flipout_weights_f32": [_i, _i, _i, _vp, _vp, _i, _l, _vp, _i, _vp, _i, _i, _vp, _vp],
     "fpn_chain_pad_units_bf16": [],
     "fpn_chain_pack_bf16": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_v1_seg_head_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],

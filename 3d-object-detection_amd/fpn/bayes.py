@@ -47,13 +47,20 @@ def init_variables(store, pc_channels=3, rho_mean=-3.0, rho_std=0.1, seed=3):
 class BayesPlan:
     """S Monte-Carlo forward passes of the Flipout network."""
 
-    def __init__(self, store, pc_channels=3, chunk_frustums=None, mc_dropout=False):
+    def __init__(self, store, pc_channels=3, chunk_frustums=None, mc_dropout=False, chain=True):
         self.store = store
         self.pc_channels = pc_channels
         self.chunk_frustums = chunk_frustums
         self.mc_dropout = mc_dropout
+        # chain: run the convolution stacks through the register-chain kernels on
+        # per-frustum effective weights (the points of a frustum share their Flipout
+        # signs, so W_mean + diag(s_in) dW diag(s_out) is ONE matrix per frustum and the
+        # layer is a plain product with it).  Monte-Carlo dropout sits between two layers
+        # of a chain and keeps the one-layer-per-launch path.
+        self.chain = chain and not mc_dropout
         init_variables(store, pc_channels)
         self.table = _plan.layer_table(pc_channels)
+        self._ones = {}
 
     # ---- noise -------------------------------------------------------------
     def sample_noise(self, nsamples, batch, generator=None):
@@ -97,6 +104,8 @@ class BayesPlan:
             raise ValueError("the fused max-pool needs the number of points per frustum to be a multiple of 32")
         if noise is None:
             noise = self.sample_noise(nsamples, b, generator)
+        if self.chain and 3 <= c <= 8:
+            return self._forward_chain(point_cloud, one_hot_vec, nsamples, noise)
         chunk = self.chunk_frustums or self.default_chunk(n)
         per_sample = []
         for s in range(nsamples):
@@ -110,6 +119,122 @@ class BayesPlan:
             per_sample.append({k: torch.cat([o[k] for o in outs], 0) if len(outs) > 1 else outs[0][k]
                                for k in outs[0]})
         return {k: torch.stack([p[k] for p in per_sample], 0) for k in per_sample[0]}
+
+    # ---- chain path -----------------------------------------------------------
+    def _one(self, width):
+        t = self._ones.get(width)
+        if t is None or t.device != self.store.device:
+            t = self._ones[width] = torch.ones(width, dtype=torch.float32, device=self.store.device)
+        return t
+
+    # frustum copies (sample x frustum pairs) per pass of the chain path: each carries
+    # 2.4 MB of effective weights
+    CHAIN_COPIES = 1024
+
+    def _forward_chain(self, point_cloud, one_hot_vec, nsamples, noise):
+        """All samples of a block of frustums stacked along the frustum axis: a pass of
+        the chain kernels works on (samples x frustums) independent "frustum copies",
+        each with its own effective weights."""
+        b, n, c = point_cloud.shape
+        budget = self.chunk_frustums or self.CHAIN_COPIES
+        sig = {k: self._sigma(k) for k, v in noise.items() if v is not None}
+        result = {}
+        for lo in range(0, b, budget):
+            hi = min(b, lo + budget)
+            bb = hi - lo
+            group = max(1, budget // bb)                 # samples per pass
+            for s0 in range(0, nsamples, group):
+                s1 = min(nsamples, s0 + group)
+                sp = s1 - s0
+                nz = {k: ((sig[k] * v[0][s0:s1]).contiguous(),
+                          v[1][s0:s1, lo:hi].reshape(sp * bb, -1).contiguous(),
+                          v[2][s0:s1, lo:hi].reshape(sp * bb, -1).contiguous())
+                      for k, v in noise.items() if v is not None}
+                pc = point_cloud[lo:hi].repeat(sp, 1, 1) if sp > 1 else point_cloud[lo:hi].contiguous()
+                oh = one_hot_vec[lo:hi].repeat(sp, 1) if sp > 1 else one_hot_vec[lo:hi].contiguous()
+                ep = self._forward_chunk_chain(pc, oh, nz, sp)
+                for k, v in ep.items():
+                    if k not in result:
+                        result[k] = torch.empty((nsamples, b) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                    result[k][s0:s1, lo:hi] = v.reshape((sp, bb) + tuple(v.shape[1:]))
+        return result
+
+    def _eff(self, scope, nz, layout, rows=None):
+        """Per-copy effective weights of a layer in a chain kernel's layout; rows: use
+        only the first `rows` input channels (conv6's point_feat part)."""
+        dw, si, so = nz[scope]
+        w = self.store[scope + "/weights"]
+        if rows is not None:
+            w, dw, si = w[:rows], dw[:, :rows], si[:, :rows]
+        return ops.flipout_weights(w, dw, si, so, layout)
+
+    def _chain_tensors(self, scopes, nz, layouts):
+        """[w_eff, ones, bias] per layer: the `layers` table of a chain kernel."""
+        t = []
+        for scope, layout in zip(scopes, layouts):
+            bias = self.store[scope + "/biases"]
+            t += [self._eff(scope, nz, layout), self._one(bias.shape[0]), bias]
+        return t
+
+    def _forward_chunk_chain(self, pc, one_hot, nz, samples):
+        """pc (samples * frustums, n, c): the frustum block repeated once per sample;
+        nz[scope] = (dw (samples,cin,cout), sign_in (copies,cin), sign_out (copies,cout))."""
+        b, n, c = pc.shape
+        dev = pc.device
+        m = model_util.NUM_OBJECT_POINT
+        st = self.store
+
+        def conv(x, scope, rpg, relu=True):        # fully connected Flipout layers: one row per copy
+            dw, si, so = nz[scope]
+            return ops.shared_mlp_flipout(x, st[scope + "/weights"], dw, x.shape[0] // samples, si, so, rpg,
+                                          scale=None, shift=st[scope + "/biases"], relu=relu)
+
+        # segmentation net (FPointNet_Bayes.py:71-96): conv1..conv5 + max-pool, then
+        # conv6..conv10 with the frustum-constant part of conv6 as a per-frustum shift
+        head = self._chain_tensors(("conv1", "conv2", "conv3", "conv4", "conv5"), nz, (0, 1, 1, 1, 1))
+        gcat = torch.zeros((b, 1024 + 3), dtype=torch.float32, device=dev)
+        gcat[:, 1024:] = one_hot
+        point_feat = torch.empty((b * n, 64), dtype=torch.float32, device=dev)
+        ops.v1_seg_head(pc.reshape(b * n, c), n, ops.pointer_table(head), point_feat, gcat, per_frustum=True)
+        dw6, si6, so6 = nz["conv6"]
+        w6 = st["conv6/weights"]
+        gshift = ops.shared_mlp_flipout(gcat, w6[64:].contiguous(), dw6[:, 64:].contiguous(), b // samples,
+                                        si6[:, 64:].contiguous(), so6, 1, scale=None, shift=st["conv6/biases"],
+                                        relu=False)
+        tail = [self._eff("conv6", nz, 1, rows=64), self._one(512)] + \
+            self._chain_tensors(("conv7", "conv8", "conv9"), nz, (1, 2, 2)) + \
+            [self._eff("conv10", nz, 0), st["conv10/biases"]]
+        logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
+        ops.v1_seg_tail(point_feat, n, gshift, ops.pointer_table(tail), logits, per_frustum=True)
+        del point_feat, head, tail
+
+        mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
+        obj2d = obj.reshape(b * m, 3)
+
+        # T-Net (FPointNet_Bayes.py:120-137)
+        tnet = self._chain_tensors(("conv-reg1-stage1", "conv-reg2-stage1", "conv-reg3-stage1"), nz, (0, 1, 1))
+        tcat = torch.zeros((b, 256 + 3), dtype=torch.float32, device=dev)
+        tcat[:, 256:] = one_hot
+        ops.v1_obj_chain(obj2d, m, False, None, ops.pointer_table(tnet), tcat, per_frustum=True)
+        t = conv(tcat, "fc1-stage1", 1)
+        t = conv(t, "fc2-stage1", 1)
+        center_delta = self._plain(t, "fc3-stage1")
+        stage1_center = center_delta + mean
+
+        # box net (FPointNet_Bayes.py:99-117); the kernel subtracts center_delta on load
+        box = self._chain_tensors(("conv-reg1", "conv-reg2", "conv-reg3", "conv-reg4"), nz, (0, 1, 1, 1))
+        bcat = torch.zeros((b, 512 + 3), dtype=torch.float32, device=dev)
+        bcat[:, 512:] = one_hot
+        ops.v1_obj_chain(obj2d, m, True, center_delta, ops.pointer_table(box), bcat, per_frustum=True)
+        t = conv(bcat, "fc1", 1)
+        t = conv(t, "fc2", 1)
+        output = self._plain(t, "fc3")
+
+        ep = {"mask_logits": logits, "mask": mask, "object_point_indices": sel, "mask_xyz_mean": mean,
+              "center_delta": center_delta, "stage1_center": stage1_center, "box_output": output}
+        model_util.parse_output_to_tensors(output, ep)
+        ep["center"] = ep["center_boxnet"] + stage1_center
+        return ep
 
     def _forward_chunk(self, pc, one_hot, nz, generator):
         b, n, c = pc.shape

@@ -122,7 +122,30 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
-def v1_seg_head(pc2d, n, table, point_feat, global_max):
+def flipout_weights(w_mean, w_delta, sign_in, sign_out, layout, out=None):
+    """Effective Flipout weights per frustum through fpn_flipout_weights_f32:
+    W_mean + diag(sign_in[f]) . W_delta[f // per] . diag(sign_out[f]) for every row f of
+    the sign matrices, in `layout` (0 row-major, 1 / 2 the chain kernels' chunk layout,
+    output-tile / input-tile major).  w_delta (S, cin, cout): S Monte-Carlo samples whose
+    frustum copies are stacked along the rows of the sign matrices (per = rows / S); it
+    may be a row slice [:, :cin] of a taller stack and sign_in a column slice of a wider
+    matrix.  Returns (rows, cin*cout)."""
+    cin, cout = w_mean.shape
+    b = sign_in.shape[0]
+    s = w_delta.shape[0]
+    if w_delta.dim() != 3 or b % s != 0 or w_delta.stride(2) != 1 or w_delta.stride(1) != cout:
+        raise ValueError("w_delta must be (samples, cin, cout) with dense matrices and samples dividing %d" % b)
+    if out is None:
+        out = torch.empty((b, cin * cout), dtype=torch.float32, device=w_mean.device)
+    with torch.cuda.device(w_mean.device):
+        _lib.check(_lib.load().fpn_flipout_weights_f32(b, cin, cout, _lib.ptr(w_mean), _lib.ptr(w_delta), b // s,
+                                                       w_delta.stride(0) if s > 1 else 0, _lib.ptr(sign_in),
+                                                       _ld(sign_in), _lib.ptr(sign_out), _ld(sign_out), int(layout),
+                                                       _lib.ptr(out), _lib.stream_of(w_mean)))
+    return out
+
+
+def v1_seg_head(pc2d, n, table, point_feat, global_max, per_frustum=False):
     """conv1..conv5 + max over each frustum's points through fpn_v1_seg_head_f32;
     global_max (frustums, >=1024) must hold zeros (or a running maximum) in its first
     1024 columns and may be a view into a wider buffer."""
@@ -131,13 +154,14 @@ def v1_seg_head(pc2d, n, table, point_feat, global_max):
     tok = obs.begin("v1_seg_head", rows, 0, 0, macs=rows * (cpc * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024)) \
         if obs is not None else None
     with torch.cuda.device(pc2d.device):
-        _lib.check(_lib.load().fpn_v1_seg_head_f32(rows, int(n), cpc, _lib.ptr(pc2d), table, _lib.ptr(point_feat),
-                                                   _lib.ptr(global_max), _ld(global_max), _lib.stream_of(pc2d)))
+        _lib.check(_lib.load().fpn_v1_seg_head_f32(rows, int(n), cpc, _lib.ptr(pc2d), table, int(bool(per_frustum)),
+                                                   _lib.ptr(point_feat), _lib.ptr(global_max), _ld(global_max),
+                                                   _lib.stream_of(pc2d)))
     if obs is not None:
         obs.end(tok)
 
 
-def v1_seg_tail(point_feat, n, gbias, table, logits):
+def v1_seg_tail(point_feat, n, gbias, table, logits, per_frustum=False):
     """conv6..conv10 through fpn_v1_seg_tail_f32; gbias (frustums,512) is conv6's
     shift with the frustum-constant part of the product folded in."""
     rows = point_feat.shape[0]
@@ -146,12 +170,13 @@ def v1_seg_tail(point_feat, n, gbias, table, logits):
         if obs is not None else None
     with torch.cuda.device(point_feat.device):
         _lib.check(_lib.load().fpn_v1_seg_tail_f32(rows, int(n), _lib.ptr(point_feat), _lib.ptr(gbias), table,
-                                                   _lib.ptr(logits), _lib.stream_of(point_feat)))
+                                                   int(bool(per_frustum)), _lib.ptr(logits),
+                                                   _lib.stream_of(point_feat)))
     if obs is not None:
         obs.end(tok)
 
 
-def v1_obj_chain(obj2d, m, box, delta, table, feat_max):
+def v1_obj_chain(obj2d, m, box, delta, table, feat_max, per_frustum=False):
     """T-Net (box=False) or box-net (box=True) convolution stack + max over the object
     points through fpn_v1_obj_chain_f32; `delta` (frustums,3) or None; feat_max
     (frustums, >=256 / >=512) zeroed (or a running maximum), possibly a view."""
@@ -162,7 +187,7 @@ def v1_obj_chain(obj2d, m, box, delta, table, feat_max):
         if obs is not None else None
     with torch.cuda.device(obj2d.device):
         _lib.check(_lib.load().fpn_v1_obj_chain_f32(rows, int(m), int(bool(box)), _lib.ptr(obj2d), _lib.ptr(delta),
-                                                    table, _lib.ptr(feat_max), _ld(feat_max),
+                                                    table, int(bool(per_frustum)), _lib.ptr(feat_max), _ld(feat_max),
                                                     _lib.stream_of(obj2d)))
     if obs is not None:
         obs.end(tok)

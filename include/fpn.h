@@ -233,9 +233,36 @@ float fpn_ball_threshold(float radius);
  *           max(previous content, max over the points of frustum f of conv5's
  *           output) - the caller ZEROES those columns before the call (or passes a
  *           running maximum, e.g. when a frustum's points arrive in several calls).
+ *   per_frustum != 0 (this and the two entry points below): every WEIGHT array of
+ *           `layers` holds one copy per frustum, back to back (frustum f's copy of a
+ *           (cin,cout) layer at float offset f*cin*cout) - the effective weights of a
+ *           Flipout pass, see fpn_flipout_weights_f32; scale / shift stay shared.
  */
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,
-                        float *point_feat, float *global_max, int ldg, void *stream);
+                        int per_frustum, float *point_feat, float *global_max, int ldg,
+                        void *stream);
+
+/*
+ * Flipout (tfp.layers.Convolution2DFlipout / DenseFlipout as used by
+ * models/FPointNet_Bayes.py:54-68) for rows that share their sign vectors - all
+ * points of a frustum do: y = x.W_mean + ((x*s_in).W_delta)*s_out is the plain
+ * product with the frustum's EFFECTIVE weights
+ *   W_eff[f] = W_mean + diag(s_in[f]) . W_delta . diag(s_out[f])        (signs are +-1)
+ * so one Monte-Carlo pass through the layer-chain kernels is: build W_eff for every
+ * frustum and chain layer, then call the fpn_v1_* kernels with per_frustum = 1.
+ *   w_mean (cin,cout) row-major; sign_in (b, ld_in >= cin), sign_out (b, ld_out >=
+ *   cout), entries +-1.  Several Monte-Carlo samples can share one call, their
+ *   frustum copies stacked along b: copy f uses the perturbation matrix
+ *   w_delta + (f / frustums_per_delta) * delta_stride (floats; each (cin,cout)
+ *   row-major; frustums_per_delta = b and any stride for a single sample).
+ *   out (b, cin*cout): frustum f's matrix in `layout` 0 = row-major, 1 = the chunk
+ *   layout of fpn_tile_weights_reg_f32 with jmajor = 0, 2 = with jmajor = 1 (cin, cout
+ *   multiples of 32 for 1 and 2).  b <= 65535.
+ */
+int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const float *w_delta,
+                            int frustums_per_delta, long delta_stride, const float *sign_in,
+                            int ld_in, const float *sign_out, int ld_out, int layout, float *out,
+                            void *stream);
 
 /*
  * Weight layout of the fpn_v1_* chain kernels, whose waves keep all activations
@@ -270,7 +297,7 @@ int fpn_tile_weights_reg_f32(int cin, int cout, int jmajor, const float *w, floa
  *   logits (rows,2).
  */
 int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_shift,
-                        const float *const *layers, float *logits, void *stream);
+                        const float *const *layers, int per_frustum, float *logits, void *stream);
 
 /*
  * Convolution stack over the object points as ONE kernel, 32 points per wave,
@@ -292,7 +319,8 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
  *           fpn_v1_seg_head_f32 - the caller zeroes columns 0..255 / 0..511 first.
  */
 int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const float *delta,
-                         const float *const *layers, float *feat_max, int ldg, void *stream);
+                         const float *const *layers, int per_frustum, float *feat_max, int ldg,
+                         void *stream);
 
 /*
  * Set-abstraction module with max pooling as ONE kernel: the grouping of

@@ -54,10 +54,11 @@ def test_flipout_layer_fold_and_two_pass(device):
         close(got.cpu().numpy(), np.concatenate(want, 0), 1e-4)
 
 
-def bayes_setup(device, B=4, N=256, seed=0):
+def bayes_setup(device, B=4, N=256, seed=0, chain=True):
     from fpn import bayes, synthetic, variables
     st = variables.VariableStore(device, seed=seed + 1)
-    bp = bayes.BayesPlan(st, 3)
+    bp = bayes.BayesPlan(st, 3, chain=chain)
+    assert bp.chain == chain
     for k in list(st.keys()):
         if k.endswith("/biases"):
             st[k] = torch.randn(st[k].shape) * 0.1
@@ -65,8 +66,12 @@ def bayes_setup(device, B=4, N=256, seed=0):
     return st, bp, pc, oh
 
 
-def test_bayes_forward_matches_textbook_flipout(device):
-    st, bp, pc, oh = bayes_setup(device)
+@pytest.mark.parametrize("chain,B,N", [(True, 4, 256), (False, 4, 256), (True, 13, 96), (True, 16, 1024)])
+def test_bayes_forward_matches_textbook_flipout(device, chain, B, N):
+    """chain=True: register-chain kernels on per-frustum effective weights (13 x 96: frustum
+    boundaries inside a workgroup and a workgroup count that is not a multiple of 8, 16 x
+    1024: the XCD-grouped block order); chain=False: one Flipout layer per launch."""
+    st, bp, pc, oh = bayes_setup(device, B=B, N=N, chain=chain)
     g = torch.Generator(device=device)
     g.manual_seed(5)
     S = 2

@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     if (hipMemcpyToSymbol(HIP_SYMBOL(fpn::g_same_chunk), &tail[0], sizeof(void *)) != hipSuccess) return 5;
 #endif
     for (int it = 0; it < 3; ++it)
-        if (fpn_v1_seg_tail_f32(rows, n, pf, gs, tail, logits, nullptr)) return 2;
+        if (fpn_v1_seg_tail_f32(rows, n, pf, gs, tail, 0, logits, nullptr)) return 2;
     if (hipDeviceSynchronize() != hipSuccess) return 3;
     const long waves = rows / 32;
     std::vector<unsigned long long> h((size_t)waves * 8);
@@ -64,7 +64,7 @@ int main(int argc, char **argv)
                              dev_random(64 * 128, .1f),   dev_random(128, 1.f),  dev_random(128, .1f),
                              dev_random(128 * 1024, .1f), dev_random(1024, 1.f), dev_random(1024, .1f)};
     for (int it = 0; it < 3; ++it)
-        if (fpn_v1_seg_head_f32(rows, n, 4, pc, head, pfo, gmax, 1024, nullptr)) return 2;
+        if (fpn_v1_seg_head_f32(rows, n, 4, pc, head, 0, pfo, gmax, 1024, nullptr)) return 2;
     if (hipDeviceSynchronize() != hipSuccess) return 3;
     if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fpn::g_reg_stamps), h.size() * 8) != hipSuccess) return 4;
     const char *hn[5] = {"conv1 (operands from memory)", "conv2 + conv3 (128 MFMA)", "point_feat store",
