@@ -869,20 +869,32 @@ __global__ void flipout_weights_kernel(int cin, int cout, int layout, const floa
     const long total = (long)cin * cout;
     const long f = blockIdx.y;
     dw += (f / per_delta) * delta_stride;      // the Monte-Carlo sample this frustum copy belongs to
-    const int nj = cin / 32, nt = cout / 32;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        int k, col;
-        if (layout == 0) {
-            k = (int)(e / cout); col = (int)(e % cout);
-        } else {
-            const int i = e & 3, l = (e >> 2) & 63, q = (e >> 8) & 3;
-            const long chunk = e >> 10;
-            const int t = layout == 2 ? (int)(chunk % nt) : (int)(chunk / nj);
-            const int j = layout == 2 ? (int)(chunk / nt) : (int)(chunk % nj);
-            k = 32 * j + 8 * q + 4 * (l >> 5) + i; col = 32 * t + (l & 31);
+    sin += f * ldi;
+    sout += f * ldo;
+    out += f * total;
+    if (layout == 0) {
+        for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < (unsigned)total; e += gridDim.x * blockDim.x) {
+            const unsigned k = e / (unsigned)cout, col = e % (unsigned)cout;
+            out[e] = wm[e] + dw[e] * (sin[k] * sout[col]);
         }
-        const long src = (long)k * cout + col;
-        out[f * total + e] = wm[src] + dw[src] * (sin[f * ldi + k] * sout[f * ldo + col]);
+        return;
+    }
+    // chunked layouts: a thread makes one 16-byte group = rows k .. k+3 of one column
+    const unsigned nj = cin / 32, nt = cout / 32;
+    for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < (unsigned)(total / 4); g += gridDim.x * blockDim.x) {
+        const unsigned l = g & 63, q = (g >> 6) & 3, chunk = g >> 8;
+        const unsigned t = layout == 2 ? chunk % nt : chunk / nj;
+        const unsigned j = layout == 2 ? chunk / nt : chunk % nj;
+        const unsigned k = 32 * j + 8 * q + 4 * (l >> 5), col = 32 * t + (l & 31);
+        const float so = sout[col];
+        const float4 si = *reinterpret_cast<const float4 *>(sin + k);
+        const size_t src = (size_t)k * cout + col;
+        float4 v;
+        v.x = wm[src] + dw[src] * (si.x * so);
+        v.y = wm[src + cout] + dw[src + cout] * (si.y * so);
+        v.z = wm[src + 2 * (size_t)cout] + dw[src + 2 * (size_t)cout] * (si.z * so);
+        v.w = wm[src + 3 * (size_t)cout] + dw[src + 3 * (size_t)cout] * (si.w * so);
+        reinterpret_cast<float4 *>(out)[g] = v;
     }
 }
 
@@ -924,6 +936,10 @@ int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const
     FPN_REQUIRE(layout == 0 || (cin % 32 == 0 && cout % 32 == 0),
                 "flipout_weights: the chunked layouts need cin (%d) and cout (%d) to be multiples of 32", cin, cout);
     FPN_REQUIRE(ld_in >= cin && ld_out >= cout, "flipout_weights: leading dimensions %d, %d too small", ld_in, ld_out);
+    FPN_REQUIRE(layout == 0 || (ld_in % 4 == 0 && (reinterpret_cast<uintptr_t>(sign_in) & 15) == 0 &&
+                                (reinterpret_cast<uintptr_t>(out) & 15) == 0),
+                "flipout_weights: the chunked layouts read sign_in and write out in 16-byte groups (ld_in %d)", ld_in);
+    FPN_REQUIRE((long)cin * cout < (1L << 31), "flipout_weights: layer too large");
     if (b == 0) return FPN_OK;
     FPN_REQUIRE(b <= 65535, "flipout_weights: at most 65535 frustums per call (%d)", b);
     FPN_REQUIRE(w_mean && w_delta && sign_in && sign_out && out, "flipout_weights: null pointer");

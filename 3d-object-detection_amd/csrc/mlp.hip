@@ -54,6 +54,9 @@ struct MlpParams {
     float *y;
     int ldy;
     float *partial;  // (row blocks, cout) when pool_rows > kBM
+    // Flipout: gridDim.y Monte-Carlo samples in one launch; sample s works on these
+    // arrays advanced by s times the stride (elements)
+    long sx, swd, ssi, sso, sgb, sy, spartial;
 };
 
 // MODE kPlain:        acc = x.w
@@ -67,8 +70,19 @@ struct MlpParams {
 //                     accumulators are multiplied by so, then x.w is added on
 //                     top - no second accumulator set.
 template <int WM, int WN, int TM, int TN, int MODE>
-__global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams p)
+__global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams pin)
 {
+    MlpParams p = pin;
+    if (MODE != kPlain) {
+        const long s = blockIdx.y;
+        p.x += s * pin.sx;
+        p.w_delta += s * pin.swd;
+        p.sign_in += s * pin.ssi;
+        p.sign_out += s * pin.sso;
+        if (p.group_bias) p.group_bias += s * pin.sgb;
+        p.y += s * pin.sy;
+        if (p.partial) p.partial += s * pin.spartial;
+    }
     constexpr int BN = WN * TN * 32;
     constexpr int BM = WM * TM * 32;  // rows per workgroup: 128, or 32 in the small-batch configuration
     static_assert(WM * WN * kWave == kMlpThreads, "4 waves");
@@ -357,28 +371,30 @@ __global__ void max_pool_rows_kernel(long groups, int c, int pool_rows, const fl
     }
 }
 
+// samples: Monte-Carlo samples stacked in one launch (grid.y; p.rows is per sample)
 template <int MODE>
-int launch_mlp(const MlpParams &p, hipStream_t st)
+int launch_mlp(const MlpParams &p, hipStream_t st, unsigned samples = 1)
 {
     const long rb = (p.rows + kBM - 1) / kBM;
     if (p.pool_rows == 0 && p.cout > 64 && rb * ((p.cout + 127) / 128) < 256) {
         // few rows (the fully connected layers: one row per frustum): 128-row tiles
         // would leave most of the chip idle, so use 32-row x 128-column tiles
         const long nblk = ((p.rows + 31) / 32) * ((p.cout + 127) / 128);
-        hipLaunchKernelGGL((shared_mlp_kernel<1, 4, 1, 1, MODE>), dim3((unsigned)nblk), dim3(kMlpThreads), 0, st, p);
+        hipLaunchKernelGGL((shared_mlp_kernel<1, 4, 1, 1, MODE>), dim3((unsigned)nblk, samples), dim3(kMlpThreads), 0, st, p);
     } else if (p.cout > 64) {
         const long nblk = rb * ((p.cout + 127) / 128);
         FPN_REQUIRE(nblk <= INT32_MAX, "shared_mlp: grid too large");
-        hipLaunchKernelGGL((shared_mlp_kernel<2, 2, 2, 2, MODE>), dim3((unsigned)nblk), dim3(kMlpThreads), 0, st, p);
+        hipLaunchKernelGGL((shared_mlp_kernel<2, 2, 2, 2, MODE>), dim3((unsigned)nblk, samples), dim3(kMlpThreads), 0, st, p);
     } else if (p.cout > 32) {
-        hipLaunchKernelGGL((shared_mlp_kernel<4, 1, 1, 2, MODE>), dim3((unsigned)rb), dim3(kMlpThreads), 0, st, p);
+        hipLaunchKernelGGL((shared_mlp_kernel<4, 1, 1, 2, MODE>), dim3((unsigned)rb, samples), dim3(kMlpThreads), 0, st, p);
     } else {
-        hipLaunchKernelGGL((shared_mlp_kernel<4, 1, 1, 1, MODE>), dim3((unsigned)rb), dim3(kMlpThreads), 0, st, p);
+        hipLaunchKernelGGL((shared_mlp_kernel<4, 1, 1, 1, MODE>), dim3((unsigned)rb, samples), dim3(kMlpThreads), 0, st, p);
     }
     int rc = check_launch("fpn_shared_mlp");
     if (rc != FPN_OK) return rc;
     if (p.pool_rows > kBM) {
-        const long groups = p.rows / p.pool_rows;
+        // the samples' partial maxima and outputs lie back to back: one pass over all
+        const long groups = p.rows / p.pool_rows * samples;
         const int blocks = (int)std::min<long>((groups * p.cout + 255) / 256, 65536);
         hipLaunchKernelGGL(pool_finish_kernel, dim3(blocks), dim3(256), 0, st, groups, p.cout,
                            p.pool_rows / kBM, p.partial, p.y, p.ldy);
@@ -467,11 +483,13 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
                 rows, rows_per_sample, rows_per_group);
     if (pool_rows) FPN_REQUIRE(rows_per_sample % pool_rows == 0, "shared_mlp_flipout: pool groups straddle samples");
     if (rows == 0) return FPN_OK;
-    // one launch per Monte-Carlo sample: each has its own weight perturbation
+    // the Monte-Carlo samples (each with its own weight perturbation) share launches:
+    // grid.y walks the samples, at most 65535 at a time
     const long nsamples = rows / rows_per_sample;
     const bool fold = rows_per_group % kBM == 0;
     const long groups_per_sample = rows_per_sample / rows_per_group;
-    for (long s = 0; s < nsamples; ++s) {
+    const size_t ws_per_sample = fpn_shared_mlp_workspace_bytes(rows_per_sample, cout, pool_rows);
+    for (long s = 0; s < nsamples; s += 65535) {
         MlpParams p{};
         p.rows = rows_per_sample; p.cin = cin; p.cout = cout;
         p.x = x + s * rows_per_sample * ldx; p.ldx = ldx;
@@ -482,9 +500,13 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
         p.group_bias = group_bias ? group_bias + s * groups_per_sample * cout : nullptr;
         p.relu = relu; p.pool_rows = pool_rows; p.ldy = ldy;
         p.y = y + (pool_rows ? (s * rows_per_sample / pool_rows) : s * rows_per_sample) * (long)ldy;
-        const size_t ws_per_sample = fpn_shared_mlp_workspace_bytes(rows_per_sample, cout, pool_rows);
         p.partial = workspace ? reinterpret_cast<float *>(static_cast<char *>(workspace) + s * ws_per_sample) : nullptr;
-        rc = fold ? launch_mlp<kFlipoutFold>(p, as_stream(stream)) : launch_mlp<kFlipoutTwoPass>(p, as_stream(stream));
+        p.sx = rows_per_sample * (long)ldx; p.swd = (long)cin * cout;
+        p.ssi = groups_per_sample * cin; p.sso = groups_per_sample * cout; p.sgb = groups_per_sample * cout;
+        p.sy = (pool_rows ? rows_per_sample / pool_rows : rows_per_sample) * (long)ldy;
+        p.spartial = (long)(ws_per_sample / sizeof(float));
+        const unsigned count = (unsigned)std::min<long>(nsamples - s, 65535);
+        rc = fold ? launch_mlp<kFlipoutFold>(p, as_stream(stream), count) : launch_mlp<kFlipoutTwoPass>(p, as_stream(stream), count);
         if (rc != FPN_OK) return rc;
     }
     return FPN_OK;

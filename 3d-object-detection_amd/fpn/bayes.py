@@ -165,7 +165,7 @@ class BayesPlan:
         dw, si, so = nz[scope]
         w = self.store[scope + "/weights"]
         if rows is not None:
-            w, dw, si = w[:rows], dw[:, :rows], si[:, :rows]
+            w, dw, si = w[:rows], dw[:, :rows], si[:, :rows].contiguous()
         return ops.flipout_weights(w, dw, si, so, layout)
 
     def _chain_tensors(self, scopes, nz, layouts):
