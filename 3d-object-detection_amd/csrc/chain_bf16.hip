@@ -1,5 +1,5 @@
 // Register-resident layer chains on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16):
-// the same chains as chain_reg.hip - a wave carries 32 points through consecutive
+// the same chains as chain_reg.hip - a wave carries its points through consecutive
 // shared-MLP layers, every layer computed transposed so that its result is already the
 // next layer's operand - with bf16 weights and bf16 activations between the layers and
 // fp32 accumulation.  Kept in fp32: the first layer of every stack (its inputs are
@@ -15,11 +15,20 @@
 // into the columns, so that an epilogue is: add the shift, clamp at zero, convert.
 //
 // Weight stream.  A UNIT is what one activation tile needs against a PAIR of output
-// tiles: 2 tiles x 2 fragments x 64 lanes x 16 bytes = 4 KiB, four MFMAs.  The units of
-// a kernel are stored back to back in exactly the order in which it consumes them
-// (layer by layer; inside a layer pair-major, input tile minor), followed by kPadUnits
-// units of padding, so that the kernel can always read a fixed number of units ahead -
-// across layer boundaries - through a ring of registers.
+// tiles: 2 tiles x 2 fragments x 64 lanes x 16 bytes = 4 KiB.  The units of a kernel are
+// stored back to back in exactly the order in which it consumes them (layer by layer;
+// inside a layer pair-major, input tile minor), followed by kPadUnits units of padding,
+// so that the kernel can always read a fixed number of units ahead - across layer
+// boundaries - through a ring of registers.
+//
+// What sets the pace is not the matrix pipe but the delivery of weight fragments into
+// registers: every MFMA needs 1 KiB of them, four waves at the MFMA's pace would pull
+// 128 bytes per clock through the CU's vector memory path, which delivers 64 (measured on
+// the seg tail: 0.56 ms as is, 0.30 ms with the re-loads removed; ring depth and
+// occupancy change nothing; staging each unit once per workgroup in LDS was slower, 0.64
+// ms - the LDS read path is no wider for this access pattern and the stage barriers
+// cost).  So where the registers allow, a wave carries NP = 2 groups of 32 points and
+// uses every fragment twice.
 #include <algorithm>
 #include <cstdint>
 #include <type_traits>
@@ -31,12 +40,16 @@ namespace fpn {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef short shortx2 __attribute__((ext_vector_type(2)));
+typedef short shortx8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWaves = 4;          // waves per workgroup: they walk the weight stream together
 constexpr int kUnitVecs = 256;     // 16-byte vectors per unit
-constexpr int kPadUnits = 8;       // read-ahead beyond the last unit of a stream
+constexpr int kPadUnits = 16;      // read-ahead beyond the last unit of a stream
+constexpr int kRing = 4;           // units in flight per wave
 
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -47,7 +60,7 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-struct Act {            // 32 channels of the wave's 32 points as two operand fragments
+struct Act {            // 32 channels of 32 points as two operand fragments
     bf16x8 m[2];
 };
 
@@ -79,12 +92,25 @@ __device__ __forceinline__ void load_const(TileConst &c, const float *__restrict
     for (int q = 0; q < 4; ++q) c.q[q] = *reinterpret_cast<const float4 *>(p + ch0 + 8 * q);
 }
 
-// relu(acc + shift) as the next layer's operand
+// relu(acc + shift) as the next layer's operand, three instructions per register pair:
+// packed add, packed conversion, and the clamp as a packed 16-bit INTEGER max with 0 on
+// the bf16 bit patterns (negative floats, -0 included, are the negative integers).
 __device__ __forceinline__ void finish(Act &o, const floatx16 &a, const TileConst &sh)
 {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        o.m[r >> 3][r & 7] = (__bf16)fmaxf(a[r] + comp(sh.q[r >> 2], r & 3), 0.f);
+    for (int s = 0; s < 2; ++s) {
+        shortx8 bits;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const int r = 8 * s + e;
+            const floatx2 y = floatx2{a[r], a[r + 1]} + floatx2{comp(sh.q[r >> 2], r & 3), comp(sh.q[r >> 2], (r & 3) + 1)};
+            const shortx2 v = __builtin_elementwise_max(__builtin_bit_cast(shortx2, __builtin_convertvector(y, bf16x2)),
+                                                        shortx2{0, 0});
+            bits[e] = v[0];
+            bits[e + 1] = v[1];
+        }
+        o.m[s] = __builtin_bit_cast(bf16x8, bits);
+    }
 }
 
 // ... or kept in fp32 (the layer before the final 128 -> 2 product)
@@ -99,77 +125,106 @@ __device__ __forceinline__ floatx16 mfma(const bf16x8 &a, const bf16x8 &b, const
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// One unit: activation tile `act` against the two output tiles of the pair.  FIRST: the
+// One unit: input tile J of each of the wave's NP point groups against the two output
+// tiles of the pair (4 NP MFMAs, every weight fragment used NP times).  FIRST: the
 // accumulators start from zero (the hardware takes the constant, no register clearing).
 // T = true: transposed product (weights are the A operand, result lane = point);
 // T = false: lane = output channel, registers = points.
-template <bool FIRST, bool T>
-__device__ __forceinline__ void unit_mfma(floatx16 &acc_a, floatx16 &acc_b, const WUnit &u, const Act &act)
+template <bool FIRST, bool T, int J, int NP, int NJ>
+__device__ __forceinline__ void unit_mfma(floatx16 (&acc)[2][NP], const WUnit &u, const Act (&in)[NP][NJ])
 {
     const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (T) {
-        acc_a = mfma(u.w[0][0], act.m[0], FIRST ? z : acc_a);
-        acc_b = mfma(u.w[1][0], act.m[0], FIRST ? z : acc_b);
-        acc_a = mfma(u.w[0][1], act.m[1], acc_a);
-        acc_b = mfma(u.w[1][1], act.m[1], acc_b);
-    } else {
-        acc_a = mfma(act.m[0], u.w[0][0], FIRST ? z : acc_a);
-        acc_b = mfma(act.m[0], u.w[1][0], FIRST ? z : acc_b);
-        acc_a = mfma(act.m[1], u.w[0][1], acc_a);
-        acc_b = mfma(act.m[1], u.w[1][1], acc_b);
-    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const floatx16 c = (FIRST && m == 0) ? z : acc[t][g];
+                acc[t][g] = T ? mfma(u.w[t][m], in[g][J].m[m], c) : mfma(in[g][J].m[m], u.w[t][m], c);
+            }
 }
 
-// Transposed layer: out[NT] = relu(W'^T . in[NJ] + shift), W' = W . diag(scale).
-// ws: the layer's first unit; the ring holds units [0, RING) of it on entry (slot
-// (R0 + i) % RING = unit i) and the first RING units after the layer on exit.  The
+// Instruction order inside a unit: the wave issues in order, and a vector-ALU or memory
+// instruction placed after the unit's last MFMA would run with the matrix pipe idle.  So
+// after each MFMA come one memory read (while there are any, NVMEM of them) and up to
+// NVALU vector-ALU instructions - they issue in the 32 cycles the MFMA occupies the pipe;
+// nothing crosses the end of the unit.
+template <int NMFMA, int NVMEM, int NVALU>
+__device__ __forceinline__ void sched_unit()
+{
+#pragma unroll
+    for (int m = 0; m < NMFMA; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, (NVMEM + NMFMA - 1) / NMFMA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Transposed layer: out[g][NT] = relu(W'^T . in[g][NJ] + shift), W' = W . diag(scale).
+// ws: the layer's first unit; the ring holds units [0, kRing) of it on entry (slot
+// (R0 + i) % kRing = unit i) and the first kRing units after the layer on exit.  The
 // epilogue of a pair rides on the first two units of the next pair; the last one is
 // exposed.  Out: Act (bf16 operand) or floatx16 (fp32).
-template <int NJ, int NT, int R0, int RING, class Out>
-__device__ __forceinline__ void layer_t(Out (&out)[NT], const Act (&in)[NJ], const bf16x8 *__restrict__ ws,
-                                        const float *__restrict__ sh, WUnit (&ring)[RING], unsigned lane, int h)
+template <int NP, int NJ, int NT, int R0, class Out>
+__device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
+                                        const float *__restrict__ sh, WUnit (&ring)[kRing], unsigned lane, int h)
 {
     static_assert(NJ >= 2 && NT % 2 == 0, "unsupported layer shape");
     constexpr int U = (NT / 2) * NJ;
-    floatx16 acc[2][2];
+    floatx16 acc[2][2][NP];
     TileConst csh[2];
     static_for<0, U>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
-        constexpr int slot = (R0 + S) % RING;
-        unit_mfma<j == 0, true>(acc[set][0], acc[set][1], ring[slot], in[j]);
-        load_unit(ring[slot], ws + (size_t)(S + RING) * kUnitVecs, lane);
-        if constexpr (tp > 0 && j < 2) finish(out[2 * (tp - 1) + j], acc[set ^ 1][j], csh[j]);
+        constexpr int slot = (R0 + S) % kRing;
+        unit_mfma<j == 0, true, j>(acc[set], ring[slot], in);
+        load_unit(ring[slot], ws + (size_t)(S + kRing) * kUnitVecs, lane);
+        if constexpr (tp > 0 && j < 2) {
+#pragma unroll
+            for (int g = 0; g < NP; ++g) finish(out[g][2 * (tp - 1) + j], acc[set ^ 1][j][g], csh[j]);
+        }
         if constexpr (j == NJ - 1) {          // shifts of this pair, wanted one unit from now
             load_const(csh[0], sh, 32 * (2 * tp) + 4 * h);
             load_const(csh[1], sh, 32 * (2 * tp + 1) + 4 * h);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        sched_unit<4 * NP, j == NJ - 1 ? 12 : 4, (tp > 0 && j < 2) ? (48 * NP + 4 * NP - 1) / (4 * NP) : 1>();
     });
     constexpr int last = (NT / 2 - 1) & 1;
-    finish(out[NT - 2], acc[last][0], csh[0]);
-    finish(out[NT - 1], acc[last][1], csh[1]);
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        finish(out[g][NT - 2], acc[last][0][g], csh[0]);
+        finish(out[g][NT - 1], acc[last][1][g], csh[1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // max over the wave's points of relu(acc + shift) for the lane's channel, merged into
 // dst[channel] with an integer atomic max (values >= +0 order like their bit patterns).
 // dst: the output row in memory, or the workgroup's LDS copy of it (see WgPool).
-__device__ __forceinline__ void max_points(const floatx16 &acc, float sh, int *dst)
+template <int NP>
+__device__ __forceinline__ void max_points(const floatx16 (&acc)[NP], float sh, int *dst)
 {
-    float m = fmaxf(acc[0], acc[1]);
+    // two chains of three-operand maxima (v_max3_f32: one instruction per two values)
+    float m0 = acc[0][0], m1 = acc[0][1];
 #pragma unroll
-    for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(acc[r], acc[r + 1]));
-    atomicMax(dst, __float_as_int(fmaxf(m + sh, 0.f)));
+    for (int g = 0; g < NP; ++g)
+#pragma unroll
+        for (int r = (g == 0 ? 2 : 0); r < 16; r += 4) {
+            m0 = fmaxf(fmaxf(m0, acc[g][r]), acc[g][r + 1]);
+            if (r + 2 < 16) m1 = fmaxf(fmaxf(m1, acc[g][r + 2]), acc[g][r + 3]);
+        }
+    atomicMax(dst, __float_as_int(fmaxf(fmaxf(m0, m1) + sh, 0.f)));
 }
 
 // Maxima over points leave a wave as one atomic per (32-channel tile, lane); at bf16
 // speed the memory-side atomic units, not the matrix cores, would set the pace (measured:
 // the seg head takes 0.82 ms with, 0.42 ms without them).  So the four waves of a
 // workgroup first merge their maxima in LDS (ds_max, no return value, nothing waits on
-// it) and the workgroup then issues one memory atomic per channel: 8x fewer.  That needs
-// every wave of the workgroup to have rows and the pooling groups (g rows each: a
-// frustum's points, a ball's samples) to tile the workgroup's 128 rows evenly; otherwise
-// the waves update memory directly.
+// it) and the workgroup then issues one memory atomic per channel.  That needs every wave
+// of the workgroup to have rows and the pooling groups (g rows each: a frustum's points,
+// a ball's samples) to tile the workgroup's rows evenly; otherwise the waves update
+// memory directly.
 struct WgPool {
     bool on;          // workgroup-uniform
     int groups;       // pooling groups inside this workgroup's rows (1, 2 or 4)
@@ -177,14 +232,15 @@ struct WgPool {
     long first;       // index of the workgroup's first group
 };
 
+template <int NP>
 __device__ __forceinline__ WgPool wg_pool(long rows, int g)
 {
-    constexpr int kRows = kWaves * 32;
+    constexpr int kRows = kWaves * 32 * NP;
     const long r0 = (long)blockIdx.x * kRows;
     WgPool w;
     w.on = r0 + kRows <= rows && (g % kRows == 0 || kRows % g == 0);
     w.groups = g >= kRows ? 1 : kRows / g;
-    w.local = g >= kRows ? 0 : (int)((threadIdx.x >> 6) * 32 / g);
+    w.local = g >= kRows ? 0 : (int)((threadIdx.x >> 6) * (32 * NP) / g);
     w.first = r0 / g;
     return w;
 }
@@ -206,30 +262,33 @@ __device__ __forceinline__ void wg_pool_flush(int (&lmax)[4 * C], const WgPool &
             atomicMax(reinterpret_cast<int *>(out + (w.first + k) * ld + ch), lmax[k * C + ch]);
 }
 
-// Last layer of a stack: gmax[0 : 32 NT] = max(gmax, max over the 32 points of
-// relu(in[NJ] . W' + shift)), four output tiles per trip of a rolled loop; the
-// reduction of one pair rides on the units of the next.  Channels >= cvalid (widths
-// padded up to a multiple of 128) are not written.
-template <int NJ, int NT, int R0, int RING>
-__device__ __forceinline__ void layer_max(const Act (&in)[NJ], const bf16x8 *__restrict__ ws,
-                                          const float *__restrict__ sh, int *gmax,
-                                          WUnit (&ring)[RING], unsigned lane, int cvalid = 32 * NT)
+// Last layer of a stack: gmax[0 : 32 NT] = max(gmax, max over the wave's points of
+// relu(in . W' + shift)), four output tiles per trip of a rolled loop; the reduction of
+// one pair rides on the units of the next.  Channels >= cvalid (widths padded up to a
+// multiple of 128) are not written.
+template <int NP, int NJ, int NT, int R0>
+__device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
+                                          const float *__restrict__ sh, int *gmax, WUnit (&ring)[kRing], unsigned lane,
+                                          int cvalid = 32 * NT)
 {
-    static_assert(NJ >= 2 && NT % 4 == 0 && (2 * NJ) % RING == 0, "unsupported layer shape");
+    static_assert(NJ >= 2 && NT % 4 == 0 && (2 * NJ) % kRing == 0, "unsupported layer shape");
     const int c = lane & 31;
-    floatx16 acc[2][2];
+    floatx16 acc[2][2][NP];
     const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    acc[1][0] = z;
-    acc[1][1] = z;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        acc[1][0][g] = z;
+        acc[1][1][g] = z;
+    }
     float rsh[2] = {0.f, 0.f};
 #pragma unroll 1
     for (int t0 = 0; t0 < NT; t0 += 4) {
         const bf16x8 *wt = ws + (size_t)(t0 / 2) * NJ * kUnitVecs;
         static_for<0, 2 * NJ>([&](auto I) {
             constexpr int S = decltype(I)::value, set = S / NJ, j = S % NJ;
-            constexpr int slot = (R0 + S) % RING;
-            unit_mfma<j == 0, false>(acc[set][0], acc[set][1], ring[slot], in[j]);
-            load_unit(ring[slot], wt + (size_t)(S + RING) * kUnitVecs, lane);
+            constexpr int slot = (R0 + S) % kRing;
+            unit_mfma<j == 0, false, j>(acc[set], ring[slot], in);
+            load_unit(ring[slot], wt + (size_t)(S + kRing) * kUnitVecs, lane);
             // the other accumulator pair holds the two tiles before these; the very first
             // time there are none (it holds zeros, and so does the shift): the update is
             // then a harmless max with 0 - no branch inside the unit
@@ -242,7 +301,7 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NJ], const bf16x8 *__r
                 rsh[0] = sh[32 * tcur + c];
                 rsh[1] = sh[32 * (tcur + 1) + c];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            sched_unit<4 * NP, j == NJ - 1 ? 6 : 4, j < 2 ? (12 * NP + 8 + 4 * NP - 1) / (4 * NP) : 1>();
         });
     }
     if (32 * (NT - 2) < cvalid) {
@@ -281,11 +340,10 @@ __device__ __forceinline__ void layer_first(Act (&out)[NT], const float (&x)[NST
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int RING>
-__device__ __forceinline__ void fill_ring(WUnit (&ring)[RING], const bf16x8 *__restrict__ ws, unsigned lane)
+__device__ __forceinline__ void fill_ring(WUnit (&ring)[kRing], const bf16x8 *__restrict__ ws, unsigned lane)
 {
 #pragma unroll
-    for (int i = 0; i < RING; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
+    for (int i = 0; i < kRing; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
 }
 
 constexpr int units_of(int cin, int cout) { return (cout / 64) * (cin / 32); }
@@ -294,6 +352,7 @@ constexpr int units_of(int cin, int cout) { return (cout / 64) * (cin / 32); }
 // seg head: conv1 .. conv5 + max over points.  Stream: conv2, conv3, conv4, conv5.
 // point_feat (conv3's output) goes to memory as the tail's operand fragments: per point
 // 64 bf16, fragment (tile t, s) of lane half h at element ((2t + s) * 2 + h) * 8.
+// A wave takes 32 NP consecutive points of one frustum.
 // ---------------------------------------------------------------------------
 struct HeadParams {
     long rows;
@@ -307,56 +366,55 @@ struct HeadParams {
     int ldg;
 };
 
-#ifndef FPN_BF16_HEAD_RING
-#define FPN_BF16_HEAD_RING 4
-#endif
-constexpr int kHeadRing = FPN_BF16_HEAD_RING;
-
-#ifndef FPN_BF16_HEAD_WPE
-#define FPN_BF16_HEAD_WPE 1
-#endif
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(FPN_BF16_HEAD_WPE, FPN_BF16_HEAD_WPE))) void seg_head_bf16_kernel(const HeadParams p)
+template <int NP>
+__global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadParams p)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     __shared__ int lmax[4 * 1024];
-    const WgPool pool = wg_pool(p.rows, p.n);
+    const WgPool pool = wg_pool<NP>(p.rows, p.n);
     if (!pool.on && row0 >= p.rows) return;
     if (pool.on) wg_pool_clear<1024>(lmax, pool);
     int *gmax = reinterpret_cast<int *>(p.gmax + (row0 / p.n) * p.ldg);
 
-    WUnit ring[kHeadRing];
+    WUnit ring[kRing];
     fill_ring(ring, p.ws, lane);
-    float x[4];
-    const float *src = p.pc + (row0 + pt) * p.cpc;
+    Act a1[NP][2], a2[NP][2], a3[NP][2], a4[NP][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) x[s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
-    Act a1[2], a2[2], a3[2], a4[4];
-    layer_first<2, 4>(a1, x, p.w1, p.cpc, p.sc1, p.sh1, lane, h);
+    for (int g = 0; g < NP; ++g) {
+        float x[4];
+        const float *src = p.pc + (row0 + 32 * g + pt) * p.cpc;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x[s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
+        layer_first<2, 4>(a1[g], x, p.w1, p.cpc, p.sc1, p.sh1, lane, h);
+    }
     constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
     const bf16x8 *ws = p.ws;
-    layer_t<2, 2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+    layer_t<NP, 2, 2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
     ws += U2 * kUnitVecs;
-    layer_t<2, 2, U2 % kHeadRing>(a3, a2, ws, p.sh3, ring, lane, h);
+    layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws, p.sh3, ring, lane, h);
     ws += U3 * kUnitVecs;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int g = 0; g < NP; ++g)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) p.point_feat[(row0 + pt) * 8 + (2 * t + s) * 2 + h] = a3[t].m[s];
-    layer_t<2, 4, (U2 + U3) % kHeadRing>(a4, a3, ws, p.sh4, ring, lane, h);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h] = a3[g][t].m[s];
+    layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, p.sh4, ring, lane, h);
     ws += U4 * kUnitVecs;
     if (pool.on) {      // (two copies of the layer: LDS and memory atomics are different instructions)
-        layer_max<4, 32, (U2 + U3 + U4) % kHeadRing>(a4, ws, p.sh5, lmax + pool.local * 1024, ring, lane);
+        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, lmax + pool.local * 1024, ring, lane);
         wg_pool_flush<1024>(lmax, pool, p.gmax, p.ldg, 1024);
     } else {
-        layer_max<4, 32, (U2 + U3 + U4) % kHeadRing>(a4, ws, p.sh5, gmax, ring, lane);
+        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, gmax, ring, lane);
     }
 }
 
 // ---------------------------------------------------------------------------
 // seg tail: conv6 (point part; the frustum part arrives as a per-frustum shift) ..
-// conv10.  Stream: conv6 (64 -> 512), conv7, conv8, conv9.
+// conv10.  Stream: conv6 (64 -> 512), conv7, conv8, conv9.  32 points per wave: conv6's
+// 512-wide output (128 registers as bf16) leaves no room for a second point group.
 // ---------------------------------------------------------------------------
 struct TailParams {
     long rows;
@@ -369,11 +427,6 @@ struct TailParams {
     float *logits;                       // (rows,2)
 };
 
-#ifndef FPN_BF16_TAIL_RING
-#define FPN_BF16_TAIL_RING 8
-#endif
-constexpr int kTailRing = FPN_BF16_TAIL_RING;
-
 __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailParams p)
 {
     const unsigned lane = threadIdx.x & 63;
@@ -381,25 +434,25 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
     const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
     if (row0 >= p.rows) return;
 
-    WUnit ring[kTailRing];
+    WUnit ring[kRing];
     fill_ring(ring, p.ws, lane);
-    Act pf[2];
+    Act pf[1][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) pf[t].m[s] = p.point_feat[(row0 + pt) * 8 + (2 * t + s) * 2 + h];
+        for (int s = 0; s < 2; ++s) pf[0][t].m[s] = p.point_feat[(row0 + pt) * 8 + (2 * t + s) * 2 + h];
 
     constexpr int U6 = units_of(64, 512), U7 = units_of(512, 256), U8 = units_of(256, 128);
     const bf16x8 *ws = p.ws;
-    Act a6[16], a7[8], a8[4];
-    floatx16 a9[4];
-    layer_t<2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, ring, lane, h);
+    Act a6[1][16], a7[1][8], a8[1][4];
+    floatx16 a9[1][4];
+    layer_t<1, 2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, ring, lane, h);
     ws += U6 * kUnitVecs;
-    layer_t<16, 8, U6 % kTailRing>(a7, a6, ws, p.sh7, ring, lane, h);
+    layer_t<1, 16, 8, U6 % kRing>(a7, a6, ws, p.sh7, ring, lane, h);
     ws += U7 * kUnitVecs;
-    layer_t<8, 4, (U6 + U7) % kTailRing>(a8, a7, ws, p.sh8, ring, lane, h);
+    layer_t<1, 8, 4, (U6 + U7) % kRing>(a8, a7, ws, p.sh8, ring, lane, h);
     ws += U8 * kUnitVecs;
-    layer_t<4, 4, (U6 + U7 + U8) % kTailRing>(a9, a8, ws, p.sh9, ring, lane, h);
+    layer_t<1, 4, 4, (U6 + U7 + U8) % kRing>(a9, a8, ws, p.sh9, ring, lane, h);
 
     // conv10 (128 -> 2, no batch norm, no ReLU) on the vector ALU in fp32: each lane half
     // sums its 64 channels, the halves meet through one cross-lane exchange
@@ -410,10 +463,10 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
         for (int q = 0; q < 4; ++q) {
             const float4 *w = reinterpret_cast<const float4 *>(p.w10 + (32 * j + 8 * q + 4 * h) * 2);
             const float4 wa = w[0], wb = w[1];
-            s0 = fmaf(a9[j][4 * q + 0], wa.x, s0); s1 = fmaf(a9[j][4 * q + 0], wa.y, s1);
-            s0 = fmaf(a9[j][4 * q + 1], wa.z, s0); s1 = fmaf(a9[j][4 * q + 1], wa.w, s1);
-            s0 = fmaf(a9[j][4 * q + 2], wb.x, s0); s1 = fmaf(a9[j][4 * q + 2], wb.y, s1);
-            s0 = fmaf(a9[j][4 * q + 3], wb.z, s0); s1 = fmaf(a9[j][4 * q + 3], wb.w, s1);
+            s0 = fmaf(a9[0][j][4 * q + 0], wa.x, s0); s1 = fmaf(a9[0][j][4 * q + 0], wa.y, s1);
+            s0 = fmaf(a9[0][j][4 * q + 1], wa.z, s0); s1 = fmaf(a9[0][j][4 * q + 1], wa.w, s1);
+            s0 = fmaf(a9[0][j][4 * q + 2], wb.x, s0); s1 = fmaf(a9[0][j][4 * q + 2], wb.y, s1);
+            s0 = fmaf(a9[0][j][4 * q + 3], wb.z, s0); s1 = fmaf(a9[0][j][4 * q + 3], wb.w, s1);
         }
     s0 += __shfl_xor(s0, 32);
     s1 += __shfl_xor(s1, 32);
@@ -434,59 +487,58 @@ struct ObjParams {
     int ldg;
 };
 
-#ifndef FPN_BF16_OBJ_RING
-#define FPN_BF16_OBJ_RING 4
-#endif
-constexpr int kObjRing = FPN_BF16_OBJ_RING;
-
-template <bool BOX>
+template <bool BOX, int NP>
 __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjParams p)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     constexpr int C = BOX ? 512 : 256;
     __shared__ int lmax[4 * C];
-    const WgPool pool = wg_pool(p.rows, p.m);
+    const WgPool pool = wg_pool<NP>(p.rows, p.m);
     if (!pool.on && row0 >= p.rows) return;
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long frustum = row0 / p.m;
     int *gmax = reinterpret_cast<int *>(p.gmax + frustum * p.ldg);
 
-    WUnit ring[kObjRing];
+    WUnit ring[kRing];
     fill_ring(ring, p.ws, lane);
-    float x[2];
-    const float *src = p.obj + (row0 + pt) * 3;
+    Act a1[NP][4], a2[NP][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int k = 2 * s + h;
-        x[s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
+    for (int g = 0; g < NP; ++g) {
+        float x[2];
+        const float *src = p.obj + (row0 + 32 * g + pt) * 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 2 * s + h;
+            x[s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
+        }
+        layer_first<4, 2>(a1[g], x, p.w1, 3, p.sc1, p.sh1, lane, h);
     }
-    Act a1[4], a2[4];
-    layer_first<4, 2>(a1, x, p.w1, 3, p.sc1, p.sh1, lane, h);
     constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
     const bf16x8 *ws = p.ws;
-    layer_t<4, 4, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+    layer_t<NP, 4, 4, 0>(a2, a1, ws, p.sh2, ring, lane, h);
     ws += U2 * kUnitVecs;
     if constexpr (!BOX) {
-        if (pool.on) layer_max<4, 8, U2 % kObjRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane);
-        else layer_max<4, 8, U2 % kObjRing>(a2, ws, p.sh3, gmax, ring, lane);
+        if (pool.on) layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane);
+        else layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, gmax, ring, lane);
     } else {
-        Act a3[8];
-        layer_t<4, 8, U2 % kObjRing>(a3, a2, ws, p.sh3, ring, lane, h);
+        Act a3[NP][8];
+        layer_t<NP, 4, 8, U2 % kRing>(a3, a2, ws, p.sh3, ring, lane, h);
         ws += U3 * kUnitVecs;
-        if (pool.on) layer_max<8, 16, (U2 + U3) % kObjRing>(a3, ws, p.sh4, lmax + pool.local * C, ring, lane);
-        else layer_max<8, 16, (U2 + U3) % kObjRing>(a3, ws, p.sh4, gmax, ring, lane);
+        if (pool.on) layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, lmax + pool.local * C, ring, lane);
+        else layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, gmax, ring, lane);
     }
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.gmax, p.ldg, C);
 }
 
 // ---------------------------------------------------------------------------
 // Set-abstraction module (models/pointnet_util.py:86-195) as one kernel, as
-// sa_chain_kernel of chain_reg.hip.  NJF > 0: the gathered point features are the first
-// layer's operand tiles (converted to bf16 on the way in) and the relative coordinates
-// ride in one more tile; stream: layer 1 ((NJF+1)*32 rows), layer 2, layer 3.
-// NJF = 0: first layer in fp32 from memory; stream: layer 2, layer 3.
+// sa_chain_kernel of chain_reg.hip; a wave takes 32 NP consecutive samples of one ball.
+// NJF > 0: the gathered point features are the first layer's operand tiles (converted to
+// bf16 on the way in) and the relative coordinates ride in one more tile; stream: layer 1
+// ((NJF+1)*32 rows), layer 2, layer 3.  NJF = 0: first layer in fp32 from memory; stream:
+// layer 2, layer 3.
 // ---------------------------------------------------------------------------
 struct SaParams {
     long rows;
@@ -500,76 +552,82 @@ struct SaParams {
     int ldo, c3;
 };
 
-constexpr int kSaRing = 4;
-
-template <int NJF, int NT1, int NT2, int NT3>
+template <int NJF, int NT1, int NT2, int NT3, int NP>
 __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaParams p)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     constexpr int C = 32 * NT3;
     __shared__ int lmax[4 * C];
-    const WgPool pool = wg_pool(p.rows, p.ns);
+    const WgPool pool = wg_pool<NP>(p.rows, p.ns);
     if (!pool.on && row0 >= p.rows) return;
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long ball = row0 / p.ns;
     const long b = ball / p.m;
-    const int pid = p.idx[row0 + pt];
     const float *ctr = p.new_xyz + ball * 3;
-    const float *src = p.xyz + (b * p.n + pid) * 3;
     int *gmax = reinterpret_cast<int *>(p.out + ball * p.ldo);
 
-    WUnit ring[kSaRing];
+    WUnit ring[kRing];
     fill_ring(ring, p.ws, lane);
     const bf16x8 *ws = p.ws;
-    Act a1[NT1], a2[NT2];
+    Act a1[NP][NT1], a2[NP][NT2];
     if constexpr (NJF > 0) {
         constexpr int NJ1 = NJF + 1;
-        Act in[NJ1];
-        const float *f = p.feat + (b * p.n + pid) * (long)p.cf;
+        Act in[NP][NJ1];
 #pragma unroll
-        for (int t = 0; t < NJF; ++t)
+        for (int g = 0; g < NP; ++g) {
+            const int pid = p.idx[row0 + 32 * g + pt];
+            const float *src = p.xyz + (b * p.n + pid) * 3;
+            const float *f = p.feat + (b * p.n + pid) * (long)p.cf;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4 *>(f + 32 * t + 8 * q + 4 * h);
-                in[t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
-                in[t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
-                in[t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
-                in[t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
-            }
-        // channels 0..2 of the last tile: elements 0..2 of fragment 0 in the lower lane half
+            for (int t = 0; t < NJF; ++t)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(f + 32 * t + 8 * q + 4 * h);
+                    in[g][t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
+                    in[g][t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
+                    in[g][t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
+                    in[g][t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
+                }
+            // channels 0..2 of the last tile: elements 0..2 of fragment 0 in the lower lane half
 #pragma unroll
-            for (int e = 0; e < 8; ++e) in[NJF].m[s][e] = (__bf16)0.f;
-        in[NJF].m[0][0] = (__bf16)(h == 0 ? src[0] - ctr[0] : 0.f);
-        in[NJF].m[0][1] = (__bf16)(h == 0 ? src[1] - ctr[1] : 0.f);
-        in[NJF].m[0][2] = (__bf16)(h == 0 ? src[2] - ctr[2] : 0.f);
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) in[g][NJF].m[s][e] = (__bf16)0.f;
+            in[g][NJF].m[0][0] = (__bf16)(h == 0 ? src[0] - ctr[0] : 0.f);
+            in[g][NJF].m[0][1] = (__bf16)(h == 0 ? src[1] - ctr[1] : 0.f);
+            in[g][NJF].m[0][2] = (__bf16)(h == 0 ? src[2] - ctr[2] : 0.f);
+        }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int U1 = (NT1 / 2) * NJ1, U2 = (NT2 / 2) * NT1;
-        layer_t<NJ1, NT1, 0>(a1, in, ws, p.shs1, ring, lane, h);
+        layer_t<NP, NJ1, NT1, 0>(a1, in, ws, p.shs1, ring, lane, h);
         ws += U1 * kUnitVecs;
-        layer_t<NT1, NT2, U1 % kSaRing>(a2, a1, ws, p.sh2, ring, lane, h);
+        layer_t<NP, NT1, NT2, U1 % kRing>(a2, a1, ws, p.sh2, ring, lane, h);
         ws += U2 * kUnitVecs;
-        if (pool.on) layer_max<NT2, NT3, (U1 + U2) % kSaRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
-        else layer_max<NT2, NT3, (U1 + U2) % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+        if (pool.on) layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
+        else layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
     } else {
-        float x[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 2 * s + h;
-            float v = 0.f;
-            if (k < 3) v = src[k] - ctr[k];
-            else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid) * (long)p.cf + k - 3];
-            x[s] = v;
+        for (int g = 0; g < NP; ++g) {
+            const int pid = p.idx[row0 + 32 * g + pt];
+            const float *src = p.xyz + (b * p.n + pid) * 3;
+            float x[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 2 * s + h;
+                float v = 0.f;
+                if (k < 3) v = src[k] - ctr[k];
+                else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid) * (long)p.cf + k - 3];
+                x[s] = v;
+            }
+            layer_first<NT1, 4>(a1[g], x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
         }
-        layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
         constexpr int U2 = (NT2 / 2) * NT1;
-        layer_t<NT1, NT2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+        layer_t<NP, NT1, NT2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
         ws += U2 * kUnitVecs;
-        if (pool.on) layer_max<NT2, NT3, U2 % kSaRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
-        else layer_max<NT2, NT3, U2 % kSaRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+        if (pool.on) layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
+        else layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
     }
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
 }
@@ -593,12 +651,31 @@ __global__ void pack_units_kernel(int cin, int cout, const float *__restrict__ w
     }
 }
 
+inline dim3 grid_for(long rows, int np)
+{
+    const long waves = rows / (32 * np);
+    return dim3((unsigned)((waves + kWaves - 1) / kWaves));
+}
+
+// two point groups per wave when a pooling group (g rows) holds whole waves of 64 rows
+inline int groups_per_wave(int g)
+{
+#ifdef FPN_BF16_NP1
+    (void)g;
+    return 1;
+#else
+    return g % 64 == 0 ? 2 : 1;
+#endif
+}
+
 template <int NJF, int NT1, int NT2, int NT3>
 int launch_sa(const SaParams &p, hipStream_t st)
 {
-    const long waves = p.rows / 32;
-    hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3>), dim3((unsigned)((waves + kWaves - 1) / kWaves)),
-                       dim3(64 * kWaves), 0, st, p);
+    const int np = groups_per_wave(p.ns);
+    if (np == 2)
+        hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 2>), grid_for(p.rows, 2), dim3(64 * kWaves), 0, st, p);
+    else
+        hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 1>), grid_for(p.rows, 1), dim3(64 * kWaves), 0, st, p);
     return check_launch("fpn_sa_chain_bf16");
 }
 
@@ -637,9 +714,10 @@ int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void 
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh2 = consts[3]; p.sh3 = consts[4]; p.sh4 = consts[5]; p.sh5 = consts[6];
     p.point_feat = reinterpret_cast<bf16x8 *>(point_feat); p.gmax = global_max; p.ldg = ldg;
-    const long waves = rows / 32;
-    hipLaunchKernelGGL(seg_head_bf16_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(64 * kWaves), 0,
-                       as_stream(stream), p);
+    if (groups_per_wave(n) == 2)
+        hipLaunchKernelGGL(seg_head_bf16_kernel<2>, grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL(seg_head_bf16_kernel<1>, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
     return check_launch("fpn_v1_seg_head_bf16");
 }
 
@@ -656,9 +734,7 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh7 = consts[0]; p.sh8 = consts[1]; p.sh9 = consts[2]; p.w10 = consts[3]; p.b10 = consts[4];
     p.logits = logits;
-    const long waves = rows / 32;
-    hipLaunchKernelGGL(seg_tail_bf16_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(64 * kWaves), 0,
-                       as_stream(stream), p);
+    hipLaunchKernelGGL(seg_tail_bf16_kernel, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
     return check_launch("fpn_v1_seg_tail_bf16");
 }
 
@@ -678,10 +754,13 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh2 = consts[3]; p.sh3 = consts[4]; p.sh4 = box ? consts[5] : nullptr;
     p.gmax = feat_max; p.ldg = ldg;
-    const long waves = rows / 32;
-    const dim3 grid((unsigned)((waves + kWaves - 1) / kWaves));
-    if (box) hipLaunchKernelGGL(obj_chain_bf16_kernel<true>, grid, dim3(64 * kWaves), 0, as_stream(stream), p);
-    else hipLaunchKernelGGL(obj_chain_bf16_kernel<false>, grid, dim3(64 * kWaves), 0, as_stream(stream), p);
+    const int np = groups_per_wave(m);
+    const dim3 grid = grid_for(rows, np), block(64 * kWaves);
+    hipStream_t st = as_stream(stream);
+    if (box && np == 2) hipLaunchKernelGGL((obj_chain_bf16_kernel<true, 2>), grid, block, 0, st, p);
+    else if (box) hipLaunchKernelGGL((obj_chain_bf16_kernel<true, 1>), grid, block, 0, st, p);
+    else if (np == 2) hipLaunchKernelGGL((obj_chain_bf16_kernel<false, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((obj_chain_bf16_kernel<false, 1>), grid, block, 0, st, p);
     return check_launch("fpn_v1_obj_chain_bf16");
 }
 

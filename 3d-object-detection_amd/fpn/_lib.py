@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfpn_hip.so")
+# FPN_LIB_PATH selects another build of the same library (tuning experiments)
+LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LIB_PATH") \
+    else os.path.join(_HERE, "libfpn_hip.so")
 
 FPN_OK = 0
 ABI_VERSION = 4
