@@ -632,6 +632,84 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
 }
 
+// ---------------------------------------------------------------------------
+// Per-point head after a feature-propagation step (fp_head_reg_kernel of chain_reg.hip):
+// [interpolated features (32 NJA) | own features (cb <= 32)] -> 128 -> 128 -> 128 -> 2.
+// Stream: layer 1 ((NJA+1)*32 rows: [xa | xb | zeros]), layer 2, layer 3; the inputs are
+// converted to bf16 on the way in, the last hidden layer stays fp32 for the final product.
+// ---------------------------------------------------------------------------
+struct FpHeadParams {
+    long rows;
+    int cb;
+    const float *xa, *xb;
+    const bf16x8 *ws;
+    const float *sh1, *sh2, *sh3;
+    const float *w4, *b4;
+    float *logits;
+};
+
+template <int NJA, int NP>
+__global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadParams p)
+{
+    constexpr int NJ = NJA + 1;
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
+    if (row0 >= p.rows) return;
+
+    WUnit ring[kRing];
+    fill_ring(ring, p.ws, lane);
+    Act in[NP][NJ], a1[NP][4], a2[NP][4];
+    floatx16 a3[NP][4];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        const float *xa = p.xa + (row0 + 32 * g + pt) * (32 * NJA);
+#pragma unroll
+        for (int t = 0; t < NJA; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(xa + 32 * t + 8 * q + 4 * h);
+                in[g][t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
+                in[g][t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
+                in[g][t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
+                in[g][t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
+            }
+        const float *xb = p.xb + (row0 + 32 * g + pt) * (long)p.cb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+            in[g][NJA].m[r >> 3][r & 7] = (__bf16)(ch < p.cb ? xb[ch] : 0.f);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int U1 = 2 * NJ, U2 = 2 * 4;
+    const bf16x8 *ws = p.ws;
+    layer_t<NP, NJ, 4, 0>(a1, in, ws, p.sh1, ring, lane, h);
+    ws += U1 * kUnitVecs;
+    layer_t<NP, 4, 4, U1 % kRing>(a2, a1, ws, p.sh2, ring, lane, h);
+    ws += U2 * kUnitVecs;
+    layer_t<NP, 4, 4, (U1 + U2) % kRing>(a3, a2, ws, p.sh3, ring, lane, h);
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 *w = reinterpret_cast<const float4 *>(p.w4 + (32 * j + 8 * q + 4 * h) * 2);
+                const float4 wa = w[0], wb = w[1];
+                s0 = fmaf(a3[g][j][4 * q + 0], wa.x, s0); s1 = fmaf(a3[g][j][4 * q + 0], wa.y, s1);
+                s0 = fmaf(a3[g][j][4 * q + 1], wa.z, s0); s1 = fmaf(a3[g][j][4 * q + 1], wa.w, s1);
+                s0 = fmaf(a3[g][j][4 * q + 2], wb.x, s0); s1 = fmaf(a3[g][j][4 * q + 2], wb.y, s1);
+                s0 = fmaf(a3[g][j][4 * q + 3], wb.z, s0); s1 = fmaf(a3[g][j][4 * q + 3], wb.w, s1);
+            }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (h == 0)
+            *reinterpret_cast<float2 *>(p.logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + p.b4[0], s1 + p.b4[1]);
+    }
+}
+
 // w (cin,cout) fp32 row-major, scale (cout) or NULL -> the layer's units:
 // element e of fragment (unit (tp, j), tile u of the pair, k-fragment s, lane (h, c)) =
 //   bf16( w[32 j + 16 s + 8 (e >> 2) + 4 h + (e & 3)][32 (2 tp + u) + c] * scale[col] ),
@@ -762,6 +840,28 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
     else if (np == 2) hipLaunchKernelGGL((obj_chain_bf16_kernel<false, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((obj_chain_bf16_kernel<false, 1>), grid, block, 0, st, p);
     return check_launch("fpn_v1_obj_chain_bf16");
+}
+
+int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const float *xb, const void *wstream,
+                           const float *const *consts, float *logits, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && rows % 32 == 0, "fp_head_chain_bf16: rows (%ld) must be a multiple of 32", rows);
+    FPN_REQUIRE(ca == 128, "fp_head_chain_bf16: %d interpolated channels, a kernel exists for 128", ca);
+    FPN_REQUIRE(cb >= 0 && cb <= 32, "fp_head_chain_bf16: at most 32 own channels per point (%d)", cb);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(xa && (cb == 0 || xb) && wstream && consts && logits, "fp_head_chain_bf16: null pointer");
+    for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "fp_head_chain_bf16: constant %d is null", i);
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(xa) & 15) == 0, "fp_head_chain_bf16: xa must be 16-byte aligned");
+    FpHeadParams p{};
+    p.rows = rows; p.cb = cb; p.xa = xa; p.xb = cb ? xb : xa;
+    p.ws = reinterpret_cast<const bf16x8 *>(wstream);
+    p.sh1 = consts[0]; p.sh2 = consts[1]; p.sh3 = consts[2]; p.w4 = consts[3]; p.b4 = consts[4];
+    p.logits = logits;
+    if (groups_per_wave((int)(rows % 64 == 0 ? 64 : 32)) == 2)
+        hipLaunchKernelGGL((fp_head_bf16_kernel<4, 2>), grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL((fp_head_bf16_kernel<4, 1>), grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+    return check_launch("fpn_fp_head_chain_bf16");
 }
 
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,

@@ -839,6 +839,72 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
 }
 
+// ---------------------------------------------------------------------------
+// Per-point head after a feature-propagation step: the concatenation
+// [interpolated features (32 NJA channels) | the point's own features (cb <= 32)]
+// (models/pointnet_util.py:218) through three 128-wide layers and a final 128 -> 2
+// product: the last FP module's MLP and the two 1-wide convolutions that follow it in a
+// PointNet++ segmentation net, as one kernel.  The concatenated tensor never exists.
+// ---------------------------------------------------------------------------
+struct FpHeadParams {
+    long rows;
+    int cb;
+    const float *xa, *xb;                       // (rows, 32 NJA), (rows, cb)
+    const float4 *w1; const float *sc1, *sh1;   // chunked ((NJA+1)*32, 128): rows [xa | xb | zeros]
+    const float4 *w2; const float *sc2, *sh2;   // chunked (128,128)
+    const float4 *w3; const float *sc3, *sh3;
+    const float *w4, *b4;                       // (128,2) row-major, (2)
+    float *logits;                              // (rows,2)
+};
+
+template <int NJA>
+__global__ __launch_bounds__(64 * kRegWaves) void fp_head_reg_kernel(const FpHeadParams p)
+{
+    constexpr int NJ = NJA + 1;
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= p.rows) return;
+
+    WChunk ring[4];
+    load_chunk(ring[0], p.w1, lane);
+    load_chunk(ring[1], p.w1 + (size_t)NJ * 256, lane);
+    floatx16 in[NJ], a1[4], a2[4], a3[4];
+    const float *xa = p.xa + (row0 + pt) * (32 * NJA);
+#pragma unroll
+    for (int t = 0; t < NJA; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(xa + 32 * t + 8 * q + 4 * h);
+            in[t][4 * q + 0] = v.x; in[t][4 * q + 1] = v.y; in[t][4 * q + 2] = v.z; in[t][4 * q + 3] = v.w;
+        }
+    const float *xb = p.xb + (row0 + pt) * (long)p.cb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = 8 * (r >> 2) + 4 * h + (r & 3);
+        in[NJA][r] = ch < p.cb ? xb[ch] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    layer_t<NJ, 4>(a1, in, p.w1, p.sc1, p.sh1, ring, p.w2, p.w2 + 4 * 256, lane, h);
+    layer_t<4, 4>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + 4 * 256, lane, h);
+    layer_t<4, 4>(a3, a2, p.w3, p.sc3, p.sh3, ring, p.w3, p.w3 + 4 * 256, lane, h);   // nothing follows: re-read
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 *w = reinterpret_cast<const float4 *>(p.w4 + (32 * j + 8 * q + 4 * h) * 2);
+            const float4 wa = w[0], wb = w[1];
+            s0 = fmaf(a3[j][4 * q + 0], wa.x, s0); s1 = fmaf(a3[j][4 * q + 0], wa.y, s1);
+            s0 = fmaf(a3[j][4 * q + 1], wa.z, s0); s1 = fmaf(a3[j][4 * q + 1], wa.w, s1);
+            s0 = fmaf(a3[j][4 * q + 2], wb.x, s0); s1 = fmaf(a3[j][4 * q + 2], wb.y, s1);
+            s0 = fmaf(a3[j][4 * q + 3], wb.z, s0); s1 = fmaf(a3[j][4 * q + 3], wb.w, s1);
+        }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    if (h == 0) *reinterpret_cast<float2 *>(p.logits + (row0 + pt) * 2) = make_float2(s0 + p.b4[0], s1 + p.b4[1]);
+}
+
 // w (cin,cout) row-major -> 4 KiB chunks for the register chains, one per
 // (32-row input tile j, 32-column output tile t):
 //   element (q, lane, i) of a chunk = w[32j + 8q + 4(lane>>5) + i][32t + (lane&31)]
@@ -1008,6 +1074,29 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
     if (njf == 10 && t1 == 2) return launch_sa_chain<10, 2, 2, 4>(p, st);
     if (njf == 10) return launch_sa_chain<10, 4, 4, 8>(p, st);
     return launch_sa_chain<4, 4, 4, 8>(p, st);
+}
+
+int fpn_fp_head_chain_f32(long rows, int ca, int cb, const float *xa, const float *xb,
+                          const float *const *layers, float *logits, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && rows % 32 == 0, "fp_head_chain: rows (%ld) must be a multiple of 32", rows);
+    FPN_REQUIRE(ca == 128, "fp_head_chain: %d interpolated channels, a kernel exists for 128", ca);
+    FPN_REQUIRE(cb >= 0 && cb <= 32, "fp_head_chain: at most 32 own channels per point (%d)", cb);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(xa && (cb == 0 || xb) && layers && logits, "fp_head_chain: null pointer");
+    for (int i = 0; i < 11; ++i) FPN_REQUIRE(layers[i], "fp_head_chain: layer parameter %d is null", i);
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(xa) & 15) == 0, "fp_head_chain: xa must be 16-byte aligned");
+    FpHeadParams p{};
+    p.rows = rows; p.cb = cb; p.xa = xa; p.xb = cb ? xb : xa;
+    p.w1 = reinterpret_cast<const float4 *>(layers[0]); p.sc1 = layers[1]; p.sh1 = layers[2];
+    p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
+    p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
+    p.w4 = layers[9]; p.b4 = layers[10];
+    p.logits = logits;
+    const long waves = rows / 32;
+    hipLaunchKernelGGL(fp_head_reg_kernel<4>, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
+                       as_stream(stream), p);
+    return check_launch("fpn_fp_head_chain_f32");
 }
 
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,

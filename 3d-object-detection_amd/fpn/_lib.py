@@ -60,6 +60,8 @@ SIGNATURES = {
     "fpn_v1_seg_tail_bf16": [_l, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_v1_obj_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "fpn_sa_chain_bf16": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "fpn_fp_head_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "fpn_fp_head_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_box3d_iou_f64": [_l, _vp, _l, _vp, _l, _vp, _vp],
     "fpn_box3d_best_overlap_f64": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -14,7 +14,8 @@ import torch
 from .. import tf_util, variables
 from ..model_util import (NUM_HEADING_BIN, NUM_SIZE_CLUSTER, get_center_regression_net,
                           parse_output_to_tensors, point_cloud_masking)
-from ..pointnet_util import pointnet_fp_module, pointnet_sa_module, pointnet_sa_module_msg
+from ..pointnet_util import (pointnet_fp_module, pointnet_fp_module_with_head, pointnet_sa_module,
+                             pointnet_sa_module_msg)
 
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "v2_config.json")) as _f:
     CONFIG = json.load(_f)
@@ -40,12 +41,11 @@ def get_instance_seg_v2_net(point_cloud, one_hot_vec, is_training, bn_decay, end
     l1_points = pointnet_fp_module(l1_xyz, l2_xyz, l1_points, l2_points, s["fp2"], is_training, bn_decay,
                                    scope='fa_layer2')
     l0_feat = torch.cat([l0_xyz, l0_points], dim=-1) if l0_points is not None else l0_xyz
-    l0_points = pointnet_fp_module(l0_xyz, l1_xyz, l0_feat, l1_points, s["fp3"], is_training, bn_decay,
-                                   scope='fa_layer3')
-    net = tf_util.conv1d(l0_points, 128, 1, padding='VALID', bn=True, is_training=is_training,
-                         scope='conv1d-fc1', bn_decay=bn_decay)
-    net = tf_util.dropout(net, is_training, 'dp1', keep_prob=s["dropout_keep"])
-    logits = tf_util.conv1d(net, 2, 1, padding='VALID', activation_fn=None, scope='conv1d-fc2')
+    # last feature propagation + conv1d(128) + dropout (identity at inference, keep_prob
+    # s["dropout_keep"] in training) + conv1d(2): one kernel when the shapes fit
+    logits = pointnet_fp_module_with_head(l0_xyz, l1_xyz, l0_feat, l1_points, s["fp3"], 128, 2, is_training,
+                                          bn_decay, scope='fa_layer3', head_scope='conv1d-fc1',
+                                          out_scope='conv1d-fc2')
     return logits, end_points
 
 

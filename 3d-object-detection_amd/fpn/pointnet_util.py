@@ -290,3 +290,78 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         b, n, c = new_points1.shape
         y = _mlp_stack(new_points1.reshape(b * n, c).contiguous(), mlp, 'conv_%d', bn)                  # :222-226
         return y.reshape(b, n, -1)
+
+
+def _fp_head_plan(store, names, cb, bn):
+    """Weights of the fused feature-propagation head in the form fpn_fp_head_chain_*
+    reads them; cached on the store until its variables change."""
+    cache = store.__dict__.setdefault("_fp_head_cache", {})
+    key = (names[0], cb, SA_PRECISION)
+    hit = cache.get(key)
+    if hit is not None and hit["version"] == store.version:
+        return hit
+    cins = (128 + cb, 128, 128)
+    params = [_layer_params(store, names[i], cins[i], 128, bn if i < 2 else True) for i in range(3)]
+    w4 = store.get_variable(names[3] + "/weights", (128, 2), "xavier")
+    b4 = store.get_variable(names[3] + "/biases", (2,), "zeros")
+    version = store.version
+    dev = w4.device
+    ones = torch.ones(128, dtype=torch.float32, device=dev)
+    w1 = torch.zeros((160, 128), dtype=torch.float32, device=dev)
+    w1[:128 + cb] = params[0][0]
+    ws = [w1, params[1][0].contiguous(), params[2][0].contiguous()]
+    scales = [ones if p[1] is None else p[1] for p in params]
+    shifts = [p[2] for p in params]
+    if SA_PRECISION == "bf16":
+        stream = ops.chain_stream_bf16(list(zip(ws, scales)))
+        tensors = shifts + [w4.contiguous(), b4]
+        plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "stream": stream}
+    else:
+        tensors = []
+        for w, sc, sh in zip(ws, scales, shifts):
+            tensors += [ops.tile_weights_reg(w, 0), sc, sh]
+        tensors += [w4.contiguous(), b4]
+        plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors)}
+    cache[key] = plan
+    return plan
+
+
+def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, num_out, is_training, bn_decay,
+                                 scope, head_scope, out_scope, bn=True):
+    """Feature propagation (pointnet_fp_module, reference pointnet_util.py:198-228) followed
+    by the two 1-wide convolutions that end a PointNet++ segmentation net:
+    conv1d(head_width) + batch norm + ReLU under `head_scope`, (dropout: identity at
+    inference,) conv1d(num_out) without activation under `out_scope`.  Returns
+    (B,n,num_out).  When the shapes fit - mlp == [128,128], head_width == 128, num_out == 2,
+    128 interpolated channels, at most 32 own channels - everything after the
+    interpolation is ONE kernel and neither the concatenated input nor any hidden layer
+    reaches memory; otherwise the layers run one call each."""
+    tf_util._inference_only(is_training)
+    b, n, _ = xyz1.shape
+    cb = 0 if points1 is None else points1.shape[2]
+    fused = (FUSE_SA and list(mlp) == [128, 128] and head_width == 128 and num_out == 2 and points2.shape[2] == 128
+             and cb <= 32 and (b * n) % 32 == 0)
+    if not fused:
+        feat = pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=bn)
+        net = tf_util.conv1d(feat, head_width, 1, padding='VALID', bn=True, is_training=is_training, scope=head_scope,
+                             bn_decay=bn_decay)
+        return tf_util.conv1d(net, num_out, 1, padding='VALID', activation_fn=None, scope=out_scope)
+    store = variables.get_default_store()
+    with variables.variable_scope(scope):
+        names = [variables.scoped('conv_0'), variables.scoped('conv_1')]
+        interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous())   # :210-215
+    names += [variables.scoped(head_scope), variables.scoped(out_scope)]
+    plan = _fp_head_plan(store, names, cb, bn)
+    rows = b * n
+    logits = torch.empty((b, n, 2), dtype=torch.float32, device=xyz1.device)
+    xb = None if points1 is None else points1.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(xyz1.device):
+        if "stream" in plan:
+            _lib.check(lib.fpn_fp_head_chain_bf16(rows, 128, cb, _lib.ptr(interpolated), _lib.ptr(xb),
+                                                  _lib.ptr(plan["stream"]), plan["table"], _lib.ptr(logits),
+                                                  _lib.stream_of(xyz1)))
+        else:
+            _lib.check(lib.fpn_fp_head_chain_f32(rows, 128, cb, _lib.ptr(interpolated), _lib.ptr(xb), plan["table"],
+                                                 _lib.ptr(logits), _lib.stream_of(xyz1)))
+    return logits

@@ -350,6 +350,23 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
                      const float *const *layers, float *out, int ldo, int c3_valid, void *stream);
 
 /*
+ * Per-point head after a feature-propagation step as ONE kernel: the MLP of
+ * pointnet_fp_module (models/pointnet_util.py:218-226) on the concatenation
+ * [interpolated features | the point's own features] followed by two 1-wide
+ * convolutions (a conv1d + batch norm + ReLU layer and the final 2-channel conv1d of a
+ * PointNet++ segmentation net), all hidden layers 128 wide:
+ *   [xa (ca = 128) | xb (cb <= 32)] -> 128 -> 128 -> 128 -> 2.
+ * The concatenated tensor is never written; every activation stays in registers.
+ *   xa (rows, 128) 16-byte aligned, xb (rows, cb) or NULL when cb == 0; rows % 32 == 0.
+ *   layers: HOST array of 11 device pointers {w1, scale1, shift1, w2, scale2, shift2,
+ *   w3, scale3, shift3, w4, bias4}: w1 = fpn_tile_weights_reg_f32(jmajor = 0) of the
+ *   (160,128) matrix whose rows are [xa's 128 | xb's cb | zero rows]; w2, w3 (128,128) in
+ *   the same layout; w4 (128,2) row-major.  logits (rows,2).
+ */
+int fpn_fp_head_chain_f32(long rows, int ca, int cb, const float *xa, const float *xb,
+                          const float *const *layers, float *logits, void *stream);
+
+/*
  * The same layer chains on the bf16 matrix instruction (fp32 accumulation): the
  * shared MLPs of models/frustum_pointnets_v1.py:41-88,108-124, models/model_util.py:
  * 335-347 and models/pointnet_util.py:116-126,187-192 with bf16 weights and bf16
@@ -394,6 +411,11 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                       const float *new_xyz, const float *feat, const int *idx, const void *wstream,
                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream);
+/* fpn_fp_head_chain_f32 in bf16: stream: layer 1 (the padded (160,128) matrix), layer 2,
+ * layer 3; consts {shift1, shift2, shift3, w4 (128,2) fp32, bias4}. */
+int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const float *xb,
+                           const void *wstream, const float *const *consts, float *logits,
+                           void *stream);
 
 /*
  * Mask, masked centroid and object-point gather of point_cloud_masking +

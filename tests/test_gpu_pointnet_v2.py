@@ -189,3 +189,42 @@ def test_sa_chain_kernels(device):
         assert outs[True].shape == wf.shape
         close(outs[True], wf)
         close(outs[True], outs[False], 1e-4)
+
+
+@pytest.mark.parametrize("cb", [4, 0, 32])
+def test_fp_head_chain(device, cb):
+    """Feature propagation + per-point head as one kernel (fp32 and bf16) against the same
+    layers run one call each; cb own channels per point (0: no skip features)."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(cb)
+    b, n, m = 3, 224, 48          # 672 rows: a last workgroup with one idle wave
+    xyz1 = rng.uniform(0, 1, (b, n, 3)).astype(np.float32)
+    xyz2 = np.ascontiguousarray(xyz1[:, :m])
+    p1 = rng.standard_normal((b, n, cb)).astype(np.float32) if cb else None
+    p2 = rng.standard_normal((b, m, 128)).astype(np.float32)
+    st = fresh_store(device, seed=4)
+    outs = {}
+    for mode in ("create", "fused", "layers", "bf16"):
+        U.FUSE_SA = mode != "layers"
+        U.SA_PRECISION = "bf16" if mode == "bf16" else "fp32"
+        try:
+            with variables.use_store(st):
+                y = U.pointnet_fp_module_with_head(dev(xyz1, device), dev(xyz2, device),
+                                                   None if p1 is None else dev(p1, device), dev(p2, device),
+                                                   [128, 128], 128, 2, False, None, scope='fa', head_scope='h1',
+                                                   out_scope='h2')
+        finally:
+            U.FUSE_SA = True
+            U.SA_PRECISION = "fp32"
+        if mode == "create":
+            st.randomize_batch_norm(6)
+            continue
+        assert y.shape == (b, n, 2)
+        outs[mode] = y.cpu().numpy()
+    assert len(st.__dict__.get("_fp_head_cache", {})) == 2, "fused kernels not taken"
+    close(outs["fused"], outs["layers"], 1e-4)
+    got, want = outs["bf16"].astype(np.float64), outs["layers"].astype(np.float64)
+    s = np.sqrt(np.mean(want ** 2))
+    err = (np.abs(got - want) / np.maximum(np.abs(want), s)).max()
+    assert 1e-6 < err <= 4e-2, err
