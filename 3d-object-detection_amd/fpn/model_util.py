@@ -1,8 +1,9 @@
 """Shared sub-graphs of the Frustum-PointNet models: counterpart of the inference
 parts of models/model_util.py (constants :14-48, tf_gather_object_pc :55-86,
 parse_output_to_tensors :211-243, point_cloud_masking :275-319,
-get_center_regression_net :322-357).  Losses, TFRecord parsers and box-corner
-helpers are training / IO code and are not part of this path.
+get_center_regression_net :322-357).  The TFRecord parsers (:89-144) live in
+fpn.frustum_records and are re-exported at the end of this module.  Losses and
+box-corner helpers are training code and are not part of this path.
 """
 import math
 
@@ -90,9 +91,56 @@ def point_cloud_masking(point_cloud, logits, end_points, xyz_only=True):
     return obj, mean, end_points
 
 
-def get_center_regression_net(object_point_cloud, one_hot_vec, is_training, bn_decay, end_points):
-    """T-Net.  Reference: model_util.py:322-357."""
+def _tnet_stack_fused(object_point_cloud, one_hot_vec):
+    """The T-Net's three convolutions + max-pool + one-hot concat as one chain kernel
+    (fpn_v1_obj_chain_f32 / _bf16) on the variables of the active store: (B,M,3) ->
+    (B, 256 + 3).  Same variables and scopes as the layer-by-layer form."""
+    from . import pointnet_util as U
+    from . import variables
+    store = variables.get_default_store()
+    b, m, _ = object_point_cloud.shape
+    scopes = ('conv-reg1-stage1', 'conv-reg2-stage1', 'conv-reg3-stage1')
+    names = [variables.scoped(s) for s in scopes]
+    cache = store.__dict__.setdefault("_tnet_chain_cache", {})
+    key = (names[0], U.SA_PRECISION)
+    plan = cache.get(key)
+    if plan is None or plan["version"] != store.version:
+        dims = ((3, 128), (128, 128), (128, 256))
+        params = [U._layer_params(store, names[i], dims[i][0], dims[i][1], True) for i in range(3)]
+        version = store.version
+        (w1, s1, h1), (w2, s2, h2), (w3, s3, h3) = [(w.contiguous(), torch.ones_like(h) if s is None else s, h)
+                                                    for w, s, h in params]
+        if U.SA_PRECISION == "bf16":
+            tensors = [w1, s1, h1, h2, h3]
+            plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors),
+                    "stream": ops.chain_stream_bf16([(w2, s2), (w3, s3)])}
+        else:
+            tensors = [w1, s1, h1, ops.tile_weights_reg(w2, 0), s2, h2, ops.tile_weights_reg(w3, 0), s3, h3]
+            plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors)}
+        cache[key] = plan
+    tcat = torch.zeros((b, 256 + 3), dtype=torch.float32, device=object_point_cloud.device)
+    tcat[:, 256:] = one_hot_vec
+    obj2d = object_point_cloud.contiguous().reshape(b * m, 3)
+    if "stream" in plan:
+        ops.v1_obj_chain_bf16(obj2d, m, False, None, plan["stream"], plan["table"], tcat)
+    else:
+        ops.v1_obj_chain(obj2d, m, False, None, plan["table"], tcat)
+    return tcat
+
+
+def get_center_regression_net(object_point_cloud, one_hot_vec, is_training, bn_decay, end_points, fused=False):
+    """T-Net.  Reference: model_util.py:322-357.  fused: run the convolution stack and
+    the max-pool as one chain kernel (object point count a multiple of 32)."""
     num_point = object_point_cloud.shape[1]
+    if fused and num_point % 32 == 0:
+        tf_util._inference_only(is_training)
+        net = _tnet_stack_fused(object_point_cloud, one_hot_vec)
+        net = tf_util.fully_connected(net, 256, scope='fc1-stage1', bn=True, is_training=is_training,
+                                      bn_decay=bn_decay)
+        net = tf_util.fully_connected(net, 128, scope='fc2-stage1', bn=True, is_training=is_training,
+                                      bn_decay=bn_decay)
+        predicted_center = tf_util.fully_connected(net, 3, activation_fn=None, scope='fc3-stage1')
+        return predicted_center, end_points
     net = object_point_cloud.unsqueeze(2)
     net = tf_util.conv2d(net, 128, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                          is_training=is_training, scope='conv-reg1-stage1', bn_decay=bn_decay)

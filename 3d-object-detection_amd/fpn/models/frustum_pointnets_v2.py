@@ -82,8 +82,9 @@ def get_model(point_cloud, one_hot_vec, is_training, bn_decay=None, cfg=None):
     end_points['mask_logits'] = logits
     object_point_cloud_xyz, mask_xyz_mean, end_points = point_cloud_masking(point_cloud, logits, end_points)
     end_points['mask_xyz_mean'] = mask_xyz_mean
+    from .. import pointnet_util
     center_delta, end_points = get_center_regression_net(object_point_cloud_xyz, one_hot_vec, is_training,
-                                                         bn_decay, end_points)
+                                                         bn_decay, end_points, fused=pointnet_util.FUSE_SA)
     end_points['center_delta'] = center_delta
     stage1_center = center_delta + mask_xyz_mean
     end_points['stage1_center'] = stage1_center
