@@ -41,19 +41,25 @@ def algorithmic_macs_per_frustum(n, m=512, pc_channels=4):
 
 
 class KernelTimer:
-    """HIP-event timer around every shared-MLP launch (events are recorded on the
-    stream the kernels are launched on: torch's current stream)."""
+    """HIP-event timer around shared-MLP launches (events are recorded on the stream the
+    kernels are launched on: torch's current stream).  `only`: names to time (the rest
+    pass untouched: a pair of events around every launch costs the step about 2 %)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.pending = []
+        self.only = only
 
     def begin(self, name, rows, cin, cout, macs=None):
+        if self.only is not None and name not in self.only:
+            return None
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         return (name, 2.0 * (macs if macs is not None else rows * cin * cout), e0, e1)
 
     def end(self, tok):
+        if tok is None:
+            return
         tok[3].record()
         self.pending.append(tok)
 
@@ -344,7 +350,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer = None if args.no_kernel_timer else KernelTimer()
+    # Inside the timed region only the dominant kernel (the segmentation tail, 43 % of the
+    # step) is bracketed by HIP events; the per-kernel table comes from three more steps
+    # after it, so that event pairs around every launch do not slow the measured step.
+    dominant = "v1_seg_tail_bf16" if bf16 else "v1_seg_tail"
+    timer = None if args.no_kernel_timer else KernelTimer(only=None if args.chunk else {dominant})
     ops.launch_observer = timer
     fence()
     t0 = time.perf_counter()
@@ -353,6 +363,13 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.launch_observer = None
+    table = None
+    if timer is not None and rank == 0:
+        table = KernelTimer()
+        ops.launch_observer = table
+        for _ in range(3):
+            net.forward(pc, one_hot)
+        ops.launch_observer = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -378,9 +395,13 @@ def main():
     if rank == 0:
         if timer is not None:
             agg = timer.summary()
+            full = table.summary()
             name = max(agg, key=lambda k: agg[k][2])
             launches, flops, secs = agg[name]
             ach = flops / secs / 1e12
+            top = max(full, key=lambda k: full[k][2])
+            if top != name:      # the timed kernel must be the one that dominates the step
+                out["roofline_note"] = "largest share of the step: %s" % top
             traffic, traffic_src = measured_traffic(name, b_local, args.points) if not args.chunk else (None, None)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic,
@@ -388,7 +409,8 @@ def main():
                                "launches": launches, "avg_launch_ms": secs / launches * 1e3,
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,
                                "share_of_step_time": secs / dt}
-            out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3} for k, v in agg.items()}
+            out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3} for k, v in full.items()}
+            out["kernels_source"] = "3 steps after the timed region, HIP events around every launch"
         if world == 1 and not args.no_pointset:
             # 256 frustums = one workgroup per CU for the per-frustum kernels (FPS, ball
             # query): latency-bound; 4096 frustums lets several workgroups share a CU
