@@ -190,6 +190,7 @@ struct SegTailRegParams {
     const float *w10, *b10;       // (128,2) row-major, (2)
     float *logits;                // (rows,2)
     int per_frustum;              // every weight array holds one copy per frustum (Flipout)
+    const unsigned *drop;         // (rows,4) keep bits of conv9's 128 outputs, or NULL
 };
 
 // The loop body of conv6-chunk kc / conv7-partial kc is 20 double steps; double step D
@@ -353,6 +354,11 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
     // ---- rest of conv9's epilogue + conv10 (128 -> 2, plain bias) on the vector ALU
     FPN_STAMP(4);
     float s0 = 0.f, s1 = 0.f;
+    // Monte-Carlo dropout before the 2-channel head (models/FPointNet_Bayes.py:92, rate
+    // 0.5 kept active at inference): bit c of word j of the point's mask keeps channel
+    // 32 j + c, kept activations count twice
+    uint4 keep = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (p.drop) keep = *reinterpret_cast<const uint4 *>(p.drop + (row0 + pt) * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j > 0) {
@@ -360,6 +366,11 @@ __global__ __launch_bounds__(64 * kRegWaves) void seg_tail_reg_kernel(const SegT
             load_const(sc, p.sc9, 32 * j + 4 * h);
             load_const(sh, p.sh9, 32 * j + 4 * h);
             bn_relu(acc9[j], sc, sh);
+        }
+        if (p.drop) {
+            const unsigned word = (j == 0 ? keep.x : j == 1 ? keep.y : j == 2 ? keep.z : keep.w) >> (4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc9[j][r] *= (word >> (8 * (r >> 2) + (r & 3))) & 1u ? 2.f : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1017,9 +1028,11 @@ int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const
 }
 
 int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_shift,
-                        const float *const *layers, int per_frustum, float *logits, void *stream)
+                        const float *const *layers, int per_frustum, const void *drop_mask, float *logits,
+                        void *stream)
 {
     FPN_REQUIRE(rows >= 0 && n >= 1, "v1_seg_tail: bad size");
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(drop_mask) & 15) == 0, "v1_seg_tail: drop_mask must be 16-byte aligned");
     FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_tail: points per frustum (%d) must be a multiple of 32", n);
     if (rows == 0) return FPN_OK;
     FPN_REQUIRE(point_feat && group_shift && layers && logits, "v1_seg_tail: null pointer");
@@ -1032,6 +1045,7 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
     p.w9 = reinterpret_cast<const float4 *>(layers[8]); p.sc9 = layers[9]; p.sh9 = layers[10];
     p.w10 = layers[11]; p.b10 = layers[12];
     p.logits = logits; p.per_frustum = per_frustum != 0;
+    p.drop = static_cast<const unsigned *>(drop_mask);
     const long waves = rows / 32;
     hipLaunchKernelGGL(seg_tail_reg_kernel, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
                        as_stream(stream), p);

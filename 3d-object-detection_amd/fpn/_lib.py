@@ -15,7 +15,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
     else os.path.join(_HERE, "libfpn_hip.so")
 
 FPN_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class FpnError(RuntimeError):
@@ -51,7 +51,7 @@ SIGNATURES = {
     "fpn_sa_chain_supported": [_i, _i, _i, _i],
     "fpn_sa_chain_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
-    "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "fpn_flipout_weights_f32": [_i, _i, _i, _vp, _vp, _i, _l, _vp, _i, _vp, _i, _i, _vp, _vp],
     "fpn_chain_pad_units_bf16": [],

@@ -44,6 +44,12 @@ def init_variables(store, pc_channels=3, rho_mean=-3.0, rho_std=0.1, seed=3):
     return store
 
 
+def unpack_keep_bits(bits):
+    """(..., 4) int32 keep bits -> (..., 128) float 0/1: bit c of word j -> channel 32j + c."""
+    shifts = torch.arange(32, device=bits.device, dtype=torch.int32)
+    return ((bits.unsqueeze(-1) >> shifts) & 1).reshape(bits.shape[:-1] + (128,)).float()
+
+
 class BayesPlan:
     """S Monte-Carlo forward passes of the Flipout network."""
 
@@ -55,17 +61,19 @@ class BayesPlan:
         # chain: run the convolution stacks through the register-chain kernels on
         # per-frustum effective weights (the points of a frustum share their Flipout
         # signs, so W_mean + diag(s_in) dW diag(s_out) is ONE matrix per frustum and the
-        # layer is a plain product with it).  Monte-Carlo dropout sits between two layers
-        # of a chain and keeps the one-layer-per-launch path.
-        self.chain = chain and not mc_dropout
+        # layer is a plain product with it).  Monte-Carlo dropout (before the 2-channel
+        # head) is a keep-bit mask applied inside the tail kernel.
+        self.chain = chain
         init_variables(store, pc_channels)
         self.table = _plan.layer_table(pc_channels)
         self._ones = {}
 
     # ---- noise -------------------------------------------------------------
-    def sample_noise(self, nsamples, batch, generator=None):
+    def sample_noise(self, nsamples, batch, generator=None, points=None):
         """All randomness of `nsamples` forward passes over `batch` frustums:
-        noise[scope] = (eps (S,cin,cout), sign_in (S,batch,cin), sign_out (S,batch,cout))."""
+        noise[scope] = (eps (S,cin,cout), sign_in (S,batch,cin), sign_out (S,batch,cout))
+        and, with mc_dropout, noise["dropout"] = (S,batch,points,4) int32 keep bits of
+        conv9's 128 outputs (bit c of word j keeps channel 32j + c; rate 0.5)."""
         dev = self.store.device
         noise = {}
         for scope, cin, cout, _, _ in self.table:
@@ -76,7 +84,11 @@ class BayesPlan:
             so = torch.randint(0, 2, (nsamples, batch, cout), device=dev, generator=generator).float() * 2 - 1
             noise[scope] = (eps, si, so)
         if self.mc_dropout:
-            noise["dropout"] = None   # drawn per chunk (one mask element per activation)
+            if points is None:
+                raise ValueError("sample_noise needs the number of points per frustum for the dropout mask")
+            bits = torch.randint(0, 1 << 32, (nsamples, batch, points, 4), dtype=torch.int64, device=dev,
+                                 generator=generator)
+            noise["dropout"] = bits.to(torch.int32)       # keeps the low 32 bits
         return noise
 
     def _sigma(self, scope):
@@ -103,19 +115,24 @@ class BayesPlan:
         if n % 32 != 0:
             raise ValueError("the fused max-pool needs the number of points per frustum to be a multiple of 32")
         if noise is None:
-            noise = self.sample_noise(nsamples, b, generator)
+            noise = self.sample_noise(nsamples, b, generator, n)
+        drop = noise.get("dropout") if self.mc_dropout else None
+        if self.mc_dropout and drop is None:
+            raise ValueError("mc_dropout needs noise['dropout'] (see sample_noise)")
+        noise = {k: v for k, v in noise.items() if k != "dropout"}
         if self.chain and 3 <= c <= 8:
-            return self._forward_chain(point_cloud, one_hot_vec, nsamples, noise)
+            return self._forward_chain(point_cloud, one_hot_vec, nsamples, noise, drop)
         chunk = self.chunk_frustums or self.default_chunk(n)
         per_sample = []
         for s in range(nsamples):
-            dws = {k: self._sigma(k) * v[0][s] for k, v in noise.items() if v is not None}
+            dws = {k: self._sigma(k) * v[0][s] for k, v in noise.items()}
             outs = []
             for lo in range(0, b, chunk):
                 hi = min(b, lo + chunk)
                 sl = {k: (dws[k], v[1][s, lo:hi].contiguous(), v[2][s, lo:hi].contiguous())
-                      for k, v in noise.items() if v is not None}
-                outs.append(self._forward_chunk(point_cloud[lo:hi], one_hot_vec[lo:hi], sl, generator))
+                      for k, v in noise.items()}
+                outs.append(self._forward_chunk(point_cloud[lo:hi], one_hot_vec[lo:hi], sl,
+                                                None if drop is None else drop[s, lo:hi]))
             per_sample.append({k: torch.cat([o[k] for o in outs], 0) if len(outs) > 1 else outs[0][k]
                                for k in outs[0]})
         return {k: torch.stack([p[k] for p in per_sample], 0) for k in per_sample[0]}
@@ -131,13 +148,13 @@ class BayesPlan:
     # 2.4 MB of effective weights
     CHAIN_COPIES = 1024
 
-    def _forward_chain(self, point_cloud, one_hot_vec, nsamples, noise):
+    def _forward_chain(self, point_cloud, one_hot_vec, nsamples, noise, drop=None):
         """All samples of a block of frustums stacked along the frustum axis: a pass of
         the chain kernels works on (samples x frustums) independent "frustum copies",
         each with its own effective weights."""
         b, n, c = point_cloud.shape
         budget = self.chunk_frustums or self.CHAIN_COPIES
-        sig = {k: self._sigma(k) for k, v in noise.items() if v is not None}
+        sig = {k: self._sigma(k) for k in noise}
         result = {}
         for lo in range(0, b, budget):
             hi = min(b, lo + budget)
@@ -149,10 +166,11 @@ class BayesPlan:
                 nz = {k: ((sig[k] * v[0][s0:s1]).contiguous(),
                           v[1][s0:s1, lo:hi].reshape(sp * bb, -1).contiguous(),
                           v[2][s0:s1, lo:hi].reshape(sp * bb, -1).contiguous())
-                      for k, v in noise.items() if v is not None}
+                      for k, v in noise.items()}
                 pc = point_cloud[lo:hi].repeat(sp, 1, 1) if sp > 1 else point_cloud[lo:hi].contiguous()
                 oh = one_hot_vec[lo:hi].repeat(sp, 1) if sp > 1 else one_hot_vec[lo:hi].contiguous()
-                ep = self._forward_chunk_chain(pc, oh, nz, sp)
+                dm = None if drop is None else drop[s0:s1, lo:hi].reshape(sp * bb * n, 4).contiguous()
+                ep = self._forward_chunk_chain(pc, oh, nz, sp, dm)
                 for k, v in ep.items():
                     if k not in result:
                         result[k] = torch.empty((nsamples, b) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
@@ -176,7 +194,7 @@ class BayesPlan:
             t += [self._eff(scope, nz, layout), self._one(bias.shape[0]), bias]
         return t
 
-    def _forward_chunk_chain(self, pc, one_hot, nz, samples):
+    def _forward_chunk_chain(self, pc, one_hot, nz, samples, drop_mask=None):
         """pc (samples * frustums, n, c): the frustum block repeated once per sample;
         nz[scope] = (dw (samples,cin,cout), sign_in (copies,cin), sign_out (copies,cout))."""
         b, n, c = pc.shape
@@ -205,7 +223,8 @@ class BayesPlan:
             self._chain_tensors(("conv7", "conv8", "conv9"), nz, (1, 2, 2)) + \
             [self._eff("conv10", nz, 0), st["conv10/biases"]]
         logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
-        ops.v1_seg_tail(point_feat, n, gshift, ops.pointer_table(tail), logits, per_frustum=True)
+        ops.v1_seg_tail(point_feat, n, gshift, ops.pointer_table(tail), logits, per_frustum=True,
+                        drop_mask=drop_mask)
         del point_feat, head, tail
 
         mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
@@ -236,7 +255,7 @@ class BayesPlan:
         ep["center"] = ep["center_boxnet"] + stage1_center
         return ep
 
-    def _forward_chunk(self, pc, one_hot, nz, generator):
+    def _forward_chunk(self, pc, one_hot, nz, drop=None):
         b, n, c = pc.shape
         dev = pc.device
         m = model_util.NUM_OBJECT_POINT
@@ -269,9 +288,8 @@ class BayesPlan:
         a = conv(a, "conv7", n)
         a = conv(a, "conv8", n)
         a = conv(a, "conv9", n)
-        if self.mc_dropout:   # layers.Dropout(rate=0.5), active (FPointNet_Bayes.py:92)
-            keep = torch.rand(a.shape, device=dev, generator=generator) >= 0.5
-            a = a * keep * 2.0
+        if drop is not None:  # layers.Dropout(rate=0.5), active (FPointNet_Bayes.py:92)
+            a = a * unpack_keep_bits(drop).reshape(b * n, 128) * 2.0
         logits = conv(a, "conv10", n, relu=False).reshape(b, n, 2)
         del a
 

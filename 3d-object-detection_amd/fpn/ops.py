@@ -161,16 +161,20 @@ def v1_seg_head(pc2d, n, table, point_feat, global_max, per_frustum=False):
         obs.end(tok)
 
 
-def v1_seg_tail(point_feat, n, gbias, table, logits, per_frustum=False):
+def v1_seg_tail(point_feat, n, gbias, table, logits, per_frustum=False, drop_mask=None):
     """conv6..conv10 through fpn_v1_seg_tail_f32; gbias (frustums,512) is conv6's
-    shift with the frustum-constant part of the product folded in."""
+    shift with the frustum-constant part of the product folded in; drop_mask (rows,4)
+    int32 keep bits of conv9's outputs (Monte-Carlo dropout) or None."""
     rows = point_feat.shape[0]
+    if drop_mask is not None and (drop_mask.dtype != torch.int32 or tuple(drop_mask.shape) != (rows, 4)
+                                  or not drop_mask.is_contiguous()):
+        raise ValueError("drop_mask must be a contiguous (rows,4) int32 tensor")
     obs = launch_observer
     tok = obs.begin("v1_seg_tail", rows, 0, 0, macs=rows * (64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2)) \
         if obs is not None else None
     with torch.cuda.device(point_feat.device):
         _lib.check(_lib.load().fpn_v1_seg_tail_f32(rows, int(n), _lib.ptr(point_feat), _lib.ptr(gbias), table,
-                                                   int(bool(per_frustum)), _lib.ptr(logits),
+                                                   int(bool(per_frustum)), _lib.ptr(drop_mask), _lib.ptr(logits),
                                                    _lib.stream_of(point_feat)))
     if obs is not None:
         obs.end(tok)

@@ -229,7 +229,7 @@ def side_config(args):
         pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
         st = variables.VariableStore(dev, seed=1)
         bayes.init_variables(st, 3)
-        bp = bayes.BayesPlan(st, 3)
+        bp = bayes.BayesPlan(st, 3, mc_dropout=args.mc_dropout)
         gen = torch.Generator(device=dev)
         gen.manual_seed(7 + rank)
 
@@ -237,7 +237,8 @@ def side_config(args):
             ep = bp.forward(pc, one_hot, args.samples, generator=gen)
             return uncertainty.mc_statistics(ep["box_output"], ep["stage1_center"])
         label = "Flipout Frustum PointNet v1, %d Monte-Carlo samples x %d frustums x %d pts per GPU, fp32, " \
-                "ensemble statistics on device" % (args.samples, b_local, points)
+                "ensemble statistics on device%s" % (args.samples, b_local, points,
+                                                     ", Monte-Carlo dropout before the head" if args.mc_dropout else "")
         metric = "frustums/sec (node) FPointNet Bayes S=%d N=%d" % (args.samples, points)
     gathered = None
     if args.graph:
@@ -301,6 +302,8 @@ def main():
                     help="v1: BASELINE config 1 (the headline metric, default); v2: PointNet++ variant, 2048 points "
                          "(config 2); bayes: Flipout v1 with --samples Monte-Carlo passes per frustum (config 3)")
     ap.add_argument("--samples", type=int, default=32, help="Monte-Carlo samples per frustum (--config bayes)")
+    ap.add_argument("--mc-dropout", action="store_true",
+                    help="--config bayes: keep the Dropout(0.5) before the segmentation head active (Monte-Carlo dropout)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="operand type of the layer-chain kernels' matrix products (accumulation is always fp32); "
                          "f32 is the headline configuration")

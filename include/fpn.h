@@ -294,10 +294,15 @@ int fpn_tile_weights_reg_f32(int cin, int cout, int jmajor, const float *w, floa
  *           w8, scale8, shift8, w9, scale9, shift9, w10, bias10} (all non-NULL);
  *           w6[0:64] and w7 in fpn_tile_weights_reg_f32 layout with jmajor = 0,
  *           w8 and w9 with jmajor = 1, w10 row-major (128,2).
+ *   drop_mask: NULL, or (rows,4) 32-bit words, 16-byte aligned: Monte-Carlo dropout before
+ *           the 2-channel head (models/FPointNet_Bayes.py:92, layers.Dropout(0.5) kept
+ *           active): bit c of word j of a point keeps conv9's channel 32j + c; kept
+ *           activations are doubled (1 / (1 - rate)), the others dropped.
  *   logits (rows,2).
  */
 int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_shift,
-                        const float *const *layers, int per_frustum, float *logits, void *stream);
+                        const float *const *layers, int per_frustum, const void *drop_mask,
+                        float *logits, void *stream);
 
 /*
  * Convolution stack over the object points as ONE kernel, 32 points per wave,

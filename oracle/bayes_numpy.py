@@ -28,9 +28,12 @@ def flipout_dense(x, params, scope, dw, s_in, s_out, rows_per_group, relu, dtype
     return np.maximum(y, 0) if relu else y
 
 
-def forward_sample(pc, one_hot, params, noise_s, dtype=np.float64, mask_override=None):
+def forward_sample(pc, one_hot, params, noise_s, dtype=np.float64, mask_override=None, dropout_keep=None):
     """One Monte-Carlo pass (FPointNet_Bayes.py:167-185).  noise_s[scope] =
-    (dW (cin,cout), s_in (B,cin), s_out (B,cout)) for every Flipout layer."""
+    (dW (cin,cout), s_in (B,cin), s_out (B,cout)) for every Flipout layer.
+    dropout_keep (B,N,128) bool, if given: layers.Dropout(rate=0.5) before the 2-channel
+    head (:92) ACTIVE, as in Monte-Carlo dropout: kept activations are scaled by
+    1 / (1 - rate) = 2, the others are zero."""
     B, N, _ = pc.shape
     M = V.NUM_OBJECT_POINT
 
@@ -51,6 +54,8 @@ def forward_sample(pc, one_hot, params, noise_s, dtype=np.float64, mask_override
     a = conv(a, "conv7", N)
     a = conv(a, "conv8", N)
     a = conv(a, "conv9", N)
+    if dropout_keep is not None:
+        a = a * np.asarray(dropout_keep, dtype).reshape(B * N, -1) * 2.0   # :92
     logits = conv(a, "conv10", N, relu=False).reshape(B, N, 2)           # :93
     obj, mean, mask, idx = V.point_cloud_masking(pc, logits, dtype=dtype, mask_override=mask_override)
     t = conv(obj.reshape(B * M, 3), "conv-reg1-stage1", M)

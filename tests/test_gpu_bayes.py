@@ -187,3 +187,35 @@ def test_keras_and_bayes_model_surfaces(device):
     assert len(o1) == 6 and not np.array_equal(o1[0], o2[0])       # every predict draws fresh weights
     assert ep["box_output"].shape == (3, 4, 59) and ep["mc_statistics"].shape == (4, 30)
     assert len(o11) == 11 and o11[1].shape == (4, 1024)
+
+
+@pytest.mark.parametrize("chain,N", [(True, 160), (False, 128)])
+def test_bayes_mc_dropout(device, chain, N):
+    """Monte-Carlo dropout before the 2-channel head (FPointNet_Bayes.py:92 kept active):
+    the keep bits are part of the noise, both paths apply them (the chain path inside the
+    tail kernel) and match the oracle given the same bits."""
+    from fpn import bayes, synthetic, variables
+    st = variables.VariableStore(device, seed=2)
+    bp = bayes.BayesPlan(st, 3, mc_dropout=True, chain=chain)
+    for k in list(st.keys()):
+        if k.endswith("/biases"):
+            st[k] = torch.randn(st[k].shape) * 0.1
+    B, S = 5, 2       # (the per-layer kernel pools groups of 32, 64 or a multiple of 128 rows)
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=4)
+    g = torch.Generator(device=device)
+    g.manual_seed(9)
+    noise = bp.sample_noise(S, B, g, N)
+    bits = noise["dropout"].cpu().numpy()
+    assert bits.shape == (S, B, N, 4) and bits.dtype == np.int32
+    keep = ((bits[..., None] >> np.arange(32)) & 1).reshape(S, B, N, 128).astype(bool)
+    assert 0.45 < keep.mean() < 0.55
+    ep = bp.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+    params = st.numpy()
+    for s in range(S):
+        nz = {k: ((torch.nn.functional.softplus(st[k + "/rho"]) + np.finfo(np.float32).eps) * v[0][s]).cpu().numpy()
+              for k, v in noise.items() if k != "dropout"}
+        nz = {k: (nz[k], noise[k][1][s].cpu().numpy(), noise[k][2][s].cpu().numpy()) for k in nz}
+        want = BN.forward_sample(pc, oh, params, nz, dropout_keep=keep[s])
+        close(ep["mask_logits"][s].cpu().numpy(), want["mask_logits"])
+        plain = BN.forward_sample(pc, oh, params, nz)
+        assert np.abs(plain["mask_logits"] - want["mask_logits"]).max() > 1e-3

@@ -34,7 +34,7 @@ int main(int argc, char **argv)
     if (hipMemcpyToSymbol(HIP_SYMBOL(fpn::g_same_chunk), &tail[0], sizeof(void *)) != hipSuccess) return 5;
 #endif
     for (int it = 0; it < 3; ++it)
-        if (fpn_v1_seg_tail_f32(rows, n, pf, gs, tail, 0, logits, nullptr)) return 2;
+        if (fpn_v1_seg_tail_f32(rows, n, pf, gs, tail, 0, nullptr, logits, nullptr)) return 2;
     if (hipDeviceSynchronize() != hipSuccess) return 3;
     const long waves = rows / 32;
     std::vector<unsigned long long> h((size_t)waves * 8);
