@@ -79,15 +79,8 @@ __device__ __forceinline__ float comp(const float4 &v, int i)
     return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
 }
 
-#ifdef FPN_REG_SAMEADDR   // diagnostic: every chunk read goes to one 4 KiB block (always in L1)
-__constant__ const float4 *g_same_chunk;
-#endif
-
 __device__ __forceinline__ void load_chunk(WChunk &c, const float4 *__restrict__ p, unsigned lane)
 {
-#ifdef FPN_REG_SAMEADDR
-    p = g_same_chunk;
-#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) c.q[q] = p[q * 64 + lane];
 }
@@ -1068,7 +1061,9 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
 {
     FPN_REQUIRE(b >= 0 && n >= 1 && m >= 1 && ns >= 1 && cf >= 0, "sa_chain: bad size");
     FPN_REQUIRE(ns % 32 == 0, "sa_chain: samples per ball (%d) must be a multiple of 32", ns);
-    FPN_REQUIRE(c3_valid >= 1 && c3_valid <= c3 && ldo >= c3_valid, "sa_chain: bad output width %d (c3 %d, ld %d)", c3_valid, c3, ldo);
+    // the last layer works on pairs of 32-channel tiles: a valid width ends on a pair
+    FPN_REQUIRE(c3_valid >= 64 && c3_valid % 64 == 0 && c3_valid <= c3 && ldo >= c3_valid,
+                "sa_chain: bad output width %d (a multiple of 64; c3 %d, ld %d)", c3_valid, c3, ldo);
     if (!fpn_sa_chain_supported(cf, c1, c2, c3))
         return fail(FPN_E_UNSUPPORTED, "sa_chain: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
     if (b == 0) return FPN_OK;

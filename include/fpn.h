@@ -345,7 +345,7 @@ int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const floa
  *               (cf+32, c1) matrix whose rows are [features, dx,dy,dz, 29 zero rows];
  *     w2 (c1,c2), w3 (c2,c3) in fpn_tile_weights_reg_f32 layout, jmajor = 0.
  *   out (b*m, ldo): columns [0, c3_valid) of row (frustum, ball) receive the running
- *   maximum (atomic max; the caller zeroes them first).  c3_valid <= c3.
+ *   maximum (atomic max; the caller zeroes them first).  c3_valid: a multiple of 64, <= c3.
  * fpn_sa_chain_supported tells whether a kernel exists for the padded shape
  * (FPN_E_UNSUPPORTED from fpn_sa_chain_f32 otherwise: use the per-layer path).
  */

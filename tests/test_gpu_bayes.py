@@ -219,3 +219,27 @@ def test_bayes_mc_dropout(device, chain, N):
         close(ep["mask_logits"][s].cpu().numpy(), want["mask_logits"])
         plain = BN.forward_sample(pc, oh, params, nz)
         assert np.abs(plain["mask_logits"] - want["mask_logits"]).max() > 1e-3
+
+
+def test_flipout_effective_weights_layouts(device):
+    """fpn_flipout_weights_f32 against W_mean + diag(s_in) dW diag(s_out) in every layout
+    (row-major, chunked output-tile major, chunked input-tile major), several samples per
+    call and a column slice as sign_in."""
+    from fpn import ops
+    rng = np.random.RandomState(3)
+    for cin, cout, layouts in ((3, 64, (0,)), (64, 128, (0, 1, 2)), (128, 2, (0,)), (96, 64, (1, 2))):
+        S, per = 3, 4
+        w = rng.standard_normal((cin, cout)).astype(np.float32)
+        dw = rng.standard_normal((S, cin, cout)).astype(np.float32)
+        si_wide = rng.choice([-1.0, 1.0], (S * per, cin + 32)).astype(np.float32)
+        so = rng.choice([-1.0, 1.0], (S * per, cout)).astype(np.float32)
+        si = si_wide[:, :cin]
+        want = w[None] + si[:, :, None] * np.repeat(dw, per, 0) * so[:, None, :]      # (copies, cin, cout)
+        si_dev = dev(si_wide, device)[:, :cin]
+        for layout in layouts:
+            got = ops.flipout_weights(dev(w, device), dev(dw, device), si_dev, dev(so, device), layout)
+            if layout == 0:
+                ref = want.reshape(S * per, -1)
+            else:
+                ref = np.stack([ops.tile_weights_reg(dev(m, device), layout == 2).cpu().numpy() for m in want])
+            np.testing.assert_array_equal(got.cpu().numpy(), ref.astype(np.float32), err_msg=str((cin, cout, layout)))

@@ -13,11 +13,7 @@ from fpn import ops, plan, synthetic, variables  # noqa: E402
 
 
 def main():
-    if os.environ.get("FPN_LIB"):          # a variant build of the library (tuning experiments)
-        from fpn import _lib
-        _lib.LIB_PATH = os.path.abspath(os.environ["FPN_LIB"])
-        print("library:", _lib.LIB_PATH, flush=True)
-    b = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    b = int(sys.argv[1]) if len(sys.argv) > 1 else 1024   # (FPN_LIB_PATH selects another build of the library)
     dev = torch.device("cuda", 0)
     st = variables.VariableStore(dev, seed=1)
     plan.init_variables(st, 4, True)

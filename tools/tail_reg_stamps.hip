@@ -30,9 +30,6 @@ int main(int argc, char **argv)
                              dev_random(256 * 128, .05f), dev_random(128, 1.f), dev_random(128, .1f),
                              dev_random(128 * 128, .1f),  dev_random(128, 1.f), dev_random(128, .1f),
                              dev_random(128 * 2, .1f),    dev_random(2, .1f)};
-#ifdef FPN_REG_SAMEADDR
-    if (hipMemcpyToSymbol(HIP_SYMBOL(fpn::g_same_chunk), &tail[0], sizeof(void *)) != hipSuccess) return 5;
-#endif
     for (int it = 0; it < 3; ++it)
         if (fpn_v1_seg_tail_f32(rows, n, pf, gs, tail, 0, nullptr, logits, nullptr)) return 2;
     if (hipDeviceSynchronize() != hipSuccess) return 3;
