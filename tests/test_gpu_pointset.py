@@ -230,3 +230,51 @@ def test_argument_errors(device):
         tf_sampling.farthest_point_sample(4, x.cpu())
     with pytest.raises(ValueError):
         tf_sampling.gather_point(x, torch.zeros((1, 2), dtype=torch.int64, device=device))
+
+
+def test_query_group_interpolate_full_size_properties(device):
+    """BASELINE v2 size (256 frustums x 2048 points, 128 centroids, 64 samples) through
+    properties that need no oracle run: every returned neighbour lies in the ball, the
+    slots are in index order and padded with the first hit, the counts are right, grouping
+    is a pure gather, the three neighbours are the three nearest in ascending order, and
+    interpolation weights sum to one; plus oracle equality on a few frustums."""
+    from fpn.tf_ops.tf_grouping import group_point, query_ball_point
+    from fpn.tf_ops.tf_interpolate import three_nn, three_nn_interpolate
+    B, N, M, NS, C, r = 256, 2048, 128, 64, 16, 0.2
+    x = clouds(B, N, seed=11, dup=0.1)
+    xyz = dev(x, device)
+    new_xyz = xyz[:, :M].contiguous()
+    feat = torch.randn((B, N, C), device=device)
+    idx, cnt = query_ball_point(r, NS, xyz, new_xyz)
+    assert idx.dtype == torch.int32 and int(idx.min()) >= 0 and int(idx.max()) < N
+    li = idx.long()
+    nb = torch.gather(xyz[:, None].expand(B, M, N, 3), 2, li[..., None].expand(B, M, NS, 3))
+    d = (nb - new_xyz[:, :, None]).pow(2).sum(-1).sqrt()
+    slot = torch.arange(NS, device=device)[None, None]
+    valid = slot < cnt[..., None]
+    assert bool((d[valid] < r * (1 + 1e-5)).all())
+    assert bool(((li[..., 1:] > li[..., :-1]) | ~valid[..., 1:]).all())        # index order
+    assert bool((li == torch.where(valid, li, li[..., :1])).all())               # padding = first hit
+    dist_all = (new_xyz[:, :, None] - xyz[:, None]).pow(2).sum(-1).sqrt()       # (B,M,N), explicit differences
+    lo = (dist_all < r * (1 - 1e-5)).sum(-1).clamp(max=NS)
+    hi = (dist_all < r * (1 + 1e-5)).sum(-1).clamp(max=NS)
+    assert bool(((cnt >= lo) & (cnt <= hi)).all()) and int(cnt.min()) >= 1     # a centroid is in its own ball
+    grouped = group_point(feat, idx)
+    assert torch.equal(grouped, torch.gather(feat[:, None].expand(B, M, N, C), 2, li[..., None].expand(B, M, NS, C)))
+
+    dist, nn = three_nn(xyz, new_xyz)                                            # unknown: all points, known: centroids
+    assert bool((dist[..., 1:] >= dist[..., :-1]).all()) and int(nn.min()) >= 0 and int(nn.max()) < M
+    known = torch.gather(new_xyz[:, None].expand(B, N, M, 3), 2, nn.long()[..., None].expand(B, N, 3, 3))
+    assert torch.allclose((known - xyz[:, :, None]).pow(2).sum(-1), dist, rtol=1e-5, atol=1e-9)
+    third = dist_all.transpose(1, 2).pow(2).kthvalue(3, dim=-1).values
+    assert torch.allclose(third, dist[..., 2], rtol=1e-4, atol=1e-7)
+    const = torch.full((B, M, 4), 3.25, device=device)
+    assert torch.allclose(three_nn_interpolate(xyz, new_xyz, const), torch.full((B, N, 4), 3.25, device=device), rtol=1e-6)
+
+    sub = [0, 101, 255]
+    oi, oc = O.query_ball_point(r, NS, x[sub], x[sub][:, :M])
+    np.testing.assert_array_equal(idx[sub].cpu().numpy(), oi)
+    np.testing.assert_array_equal(cnt[sub].cpu().numpy(), oc)
+    od, on = O.three_nn(x[sub], x[sub][:, :M])
+    np.testing.assert_array_equal(nn[sub].cpu().numpy(), on)
+    np.testing.assert_array_equal(dist[sub].cpu().numpy(), od)
