@@ -178,3 +178,21 @@ def test_hip_graph_replay_matches_eager(device):
         want = net.forward(dev(pc, device), dev(oh, device))
         for k in keys:
             assert torch.equal(got[k], want[k]), k
+
+
+def test_v1_full_size_properties(device):
+    """BASELINE config 1 size (1024 frustums x 1024 points): frustums are independent, so
+    a frustum's results do not depend on what else is in the batch (bit for bit), and a
+    sample of frustums matches the CPU oracle."""
+    from fpn import plan, synthetic
+    st = make_store(device, seed=31)
+    net = plan.V1Plan(st, 4, True)
+    pc, one_hot = synthetic.make_frustums(1024, 1024, 4, seed=5)
+    full = net.forward(dev(pc, device), dev(one_hot, device))
+    sub = [0, 17, 500, 1023]
+    alone = net.forward(dev(pc[sub], device), dev(one_hot[sub], device))
+    for k in ("mask_logits", "box_output", "center", "stage1_center", "mask"):
+        assert torch.equal(full[k][sub], alone[k]), k
+    assert torch.isfinite(full["box_output"]).all() and torch.isfinite(full["mask_logits"]).all()
+    want = V.get_model(pc[sub], one_hot[sub], st.numpy())
+    compare_end_points(alone, want, pc[sub], one_hot[sub], st.numpy())
