@@ -202,8 +202,8 @@ def side_config(args):
     from fpn import synthetic, variables
     if args.config == "v2":
         from fpn.models import frustum_pointnets_v2 as M2
-        b_local = args.batch if args.batch != 1024 else 256
-        points = args.points if args.points != 1024 else 2048
+        b_local = args.batch or 256
+        points = args.points or 2048
         pc_np, oh_np = synthetic.make_frustums(b_local, points, 4, seed=rank)
         pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
         st = variables.VariableStore(dev, seed=1)
@@ -223,8 +223,8 @@ def side_config(args):
         metric = "frustums/sec (node) FPointNet v2 N=%d" % points
     else:
         from fpn import bayes, uncertainty
-        b_local = args.batch if args.batch != 1024 else 128
-        points = args.points
+        b_local = args.batch or 128
+        points = args.points or 1024
         pc_np, oh_np = synthetic.make_frustums(b_local, points, 3, seed=rank)
         pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
         st = variables.VariableStore(dev, seed=1)
@@ -292,8 +292,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="frustums per GPU")
-    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frustums per GPU (default: 1024 for v1, 256 for v2, 128 for bayes)")
+    ap.add_argument("--points", type=int, default=None, help="points per frustum (default: 1024; 2048 for v2)")
     ap.add_argument("--chunk", type=int, default=0, help="frustums per chunk (0 = plan default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -330,7 +331,8 @@ def main():
     bf16 = args.dtype == "bf16"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     net = plan.V1Plan(st, 4, True, chunk_frustums=args.chunk or None, precision="bf16" if bf16 else "fp32")
-    b_local = args.batch
+    b_local = args.batch or 1024
+    args.points = args.points or 1024
     pc_np, oh_np = synthetic.make_frustums(b_local, args.points, 4, seed=rank)
     pc = torch.from_numpy(pc_np).to(dev)
     one_hot = torch.from_numpy(oh_np).to(dev)
