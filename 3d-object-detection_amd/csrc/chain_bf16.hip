@@ -232,11 +232,27 @@ struct WgPool {
     long first;       // index of the workgroup's first group
 };
 
+// Flipout: each frustum copy has its own weight stream (fpn_flipout_stream_bf16).  Its
+// workgroups are then placed on ONE XCD (consecutive workgroup ids go round the eight
+// XCDs, so id i handles logical block (i % 8) * (grid / 8) + i / 8) and read the copy out
+// of that XCD's L2.
+__device__ __forceinline__ unsigned logical_block(long per_frustum)
+{
+    const unsigned g = gridDim.x, i = blockIdx.x;
+    return (per_frustum && g % 8 == 0) ? (i % 8) * (g / 8) + i / 8 : i;
+}
+
+// a wave-uniform index as a scalar (the wave number comes from threadIdx)
+__device__ __forceinline__ size_t scalar_index(long v)
+{
+    return (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 template <int NP>
-__device__ __forceinline__ WgPool wg_pool(long rows, int g)
+__device__ __forceinline__ WgPool wg_pool(long rows, int g, unsigned block)
 {
     constexpr int kRows = kWaves * 32 * NP;
-    const long r0 = (long)blockIdx.x * kRows;
+    const long r0 = (long)block * kRows;
     WgPool w;
     w.on = r0 + kRows <= rows && (g % kRows == 0 || kRows % g == 0);
     w.groups = g >= kRows ? 1 : kRows / g;
@@ -364,17 +380,25 @@ struct HeadParams {
     bf16x8 *point_feat;
     float *gmax;
     int ldg;
+    long copy_vecs;     // > 0: one stream (and one w1) per frustum, this many 16-byte vectors apart
 };
 
 template <int NP>
-__global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadParams p)
+__global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
+    const unsigned block = logical_block(pin.copy_vecs);
+    const long row0 = ((long)block * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     __shared__ int lmax[4 * 1024];
-    const WgPool pool = wg_pool<NP>(p.rows, p.n);
-    if (!pool.on && row0 >= p.rows) return;
+    const WgPool pool = wg_pool<NP>(pin.rows, pin.n, block);
+    if (!pool.on && row0 >= pin.rows) return;
+    HeadParams p = pin;
+    if (pin.copy_vecs) {
+        const size_t f = scalar_index(row0 / pin.n);
+        p.ws += f * pin.copy_vecs;
+        p.w1 += f * (size_t)(pin.cpc * 64);
+    }
     if (pool.on) wg_pool_clear<1024>(lmax, pool);
     int *gmax = reinterpret_cast<int *>(p.gmax + (row0 / p.n) * p.ldg);
 
@@ -425,14 +449,22 @@ struct TailParams {
     const float *sh7, *sh8, *sh9;
     const float *w10, *b10;              // (128,2), (2)
     float *logits;                       // (rows,2)
+    long copy_vecs;                      // > 0: one stream (and one w10) per frustum
+    const unsigned *drop;                // (rows,4) keep bits of conv9's outputs, or NULL
 };
 
-__global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailParams p)
+__global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= p.rows) return;
+    const long row0 = ((long)logical_block(pin.copy_vecs) * kWaves + (threadIdx.x >> 6)) * 32;
+    if (row0 >= pin.rows) return;
+    TailParams p = pin;
+    if (pin.copy_vecs) {
+        const size_t f = scalar_index(row0 / pin.n);
+        p.ws += f * pin.copy_vecs;
+        p.w10 += f * (128 * 2);
+    }
 
     WUnit ring[kRing];
     fill_ring(ring, p.ws, lane);
@@ -454,6 +486,17 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
     ws += U8 * kUnitVecs;
     layer_t<1, 4, 4, (U6 + U7 + U8) % kRing>(a9, a8, ws, p.sh9, ring, lane, h);
 
+    // Monte-Carlo dropout before the head (models/FPointNet_Bayes.py:92): bit c of word j
+    // of the point's mask keeps channel 32 j + c, kept activations count twice
+    if (p.drop) {
+        const uint4 keep = *reinterpret_cast<const uint4 *>(p.drop + (row0 + pt) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned word = (j == 0 ? keep.x : j == 1 ? keep.y : j == 2 ? keep.z : keep.w) >> (4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a9[0][j][r] *= (word >> (8 * (r >> 2) + (r & 3))) & 1u ? 2.f : 0.f;
+        }
+    }
     // conv10 (128 -> 2, no batch norm, no ReLU) on the vector ALU in fp32: each lane half
     // sums its 64 channels, the halves meet through one cross-lane exchange
     float s0 = 0.f, s1 = 0.f;
@@ -485,18 +528,26 @@ struct ObjParams {
     const float *sh2, *sh3, *sh4;
     float *gmax;
     int ldg;
+    long copy_vecs;                    // > 0: one stream (and one w1) per frustum
 };
 
 template <bool BOX, int NP>
-__global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjParams p)
+__global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
+    const unsigned block = logical_block(pin.copy_vecs);
+    const long row0 = ((long)block * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     constexpr int C = BOX ? 512 : 256;
     __shared__ int lmax[4 * C];
-    const WgPool pool = wg_pool<NP>(p.rows, p.m);
-    if (!pool.on && row0 >= p.rows) return;
+    const WgPool pool = wg_pool<NP>(pin.rows, pin.m, block);
+    if (!pool.on && row0 >= pin.rows) return;
+    ObjParams p = pin;
+    if (pin.copy_vecs) {
+        const size_t f = scalar_index(row0 / pin.m);
+        p.ws += f * pin.copy_vecs;
+        p.w1 += f * (3 * 128);
+    }
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long frustum = row0 / p.m;
     int *gmax = reinterpret_cast<int *>(p.gmax + frustum * p.ldg);
@@ -560,7 +611,7 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
     const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     constexpr int C = 32 * NT3;
     __shared__ int lmax[4 * C];
-    const WgPool pool = wg_pool<NP>(p.rows, p.ns);
+    const WgPool pool = wg_pool<NP>(p.rows, p.ns, blockIdx.x);
     if (!pool.on && row0 >= p.rows) return;
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long ball = row0 / p.ns;
@@ -729,6 +780,35 @@ __global__ void pack_units_kernel(int cin, int cout, const float *__restrict__ w
     }
 }
 
+// Flipout: the units of one layer for every frustum copy f,
+//   W_eff[f] = W_mean + diag(sign_in[f]) . dW[f / frustums_per_delta] . diag(sign_out[f]),
+// converted to bf16 in the element order of pack_units_kernel.  One thread writes one
+// 16-byte vector; blockIdx.y = copy.
+__global__ __launch_bounds__(256) void flipout_units_kernel(int cin, int cout, const float *__restrict__ w_mean,
+                                                            const float *__restrict__ w_delta, int frustums_per_delta,
+                                                            long delta_stride, const float *__restrict__ sign_in,
+                                                            int ld_in, const float *__restrict__ sign_out, int ld_out,
+                                                            bf16x8 *__restrict__ dst, long copy_vecs, long copy0)
+{
+    const long f = copy0 + blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= cin * cout / 8) return;
+    const int nj = cin / 32;
+    const int l = v & 63, s = (v >> 6) & 1, u = (v >> 7) & 1, unit = v >> 8;
+    const int tp = unit / nj, j = unit % nj;
+    const int col = 32 * (2 * tp + u) + (l & 31), k0 = 32 * j + 16 * s + 4 * (l >> 5);
+    const float *dw = w_delta + (f / frustums_per_delta) * delta_stride;
+    const float so = sign_out[f * ld_out + col];
+    const float *si = sign_in + f * ld_in;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + 8 * (e >> 2) + (e & 3);
+        o[e] = (__bf16)fmaf(dw[(long)k * cout + col], si[k] * so, w_mean[(long)k * cout + col]);
+    }
+    dst[f * copy_vecs + v] = o;
+}
+
 inline dim3 grid_for(long rows, int np)
 {
     const long waves = rows / (32 * np);
@@ -777,9 +857,31 @@ int fpn_chain_pack_bf16(int cin, int cout, const float *w, const float *scale, v
     return check_launch("fpn_chain_pack_bf16");
 }
 
-int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void *wstream, const float *const *consts,
-                         void *point_feat, float *global_max, int ldg, void *stream)
+int fpn_flipout_stream_bf16(long copies, int cin, int cout, const float *w_mean, const float *w_delta,
+                            int frustums_per_delta, long delta_stride, const float *sign_in, int ld_in,
+                            const float *sign_out, int ld_out, void *units, long copy_vecs, void *stream)
 {
+    FPN_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 64 && cout % 64 == 0,
+                "flipout_stream_bf16: cin (%d) must be a multiple of 32 and cout (%d) of 64", cin, cout);
+    FPN_REQUIRE(copies >= 0 && frustums_per_delta >= 1 && ld_in >= cin && ld_out >= cout &&
+                    copy_vecs >= (long)cin * cout / 8,
+                "flipout_stream_bf16: bad size or stride");
+    if (copies == 0) return FPN_OK;
+    FPN_REQUIRE(w_mean && w_delta && sign_in && sign_out && units, "flipout_stream_bf16: null pointer");
+    const unsigned gx = (unsigned)((cin * cout / 8 + 255) / 256);
+    for (long c0 = 0; c0 < copies; c0 += 65535) {
+        const unsigned gy = (unsigned)std::min<long>(65535, copies - c0);
+        hipLaunchKernelGGL(flipout_units_kernel, dim3(gx, gy), dim3(256), 0, as_stream(stream), cin, cout, w_mean, w_delta,
+                           frustums_per_delta, delta_stride, sign_in, ld_in, sign_out, ld_out,
+                           reinterpret_cast<bf16x8 *>(units), copy_vecs, c0);
+    }
+    return check_launch("fpn_flipout_stream_bf16");
+}
+
+int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void *wstream, const float *const *consts,
+                         long copy_vecs, void *point_feat, float *global_max, int ldg, void *stream)
+{
+    FPN_REQUIRE(copy_vecs >= 0, "v1_seg_head_bf16: negative stream stride");
     FPN_REQUIRE(rows >= 0 && n >= 1 && cpc >= 3 && cpc <= 8, "v1_seg_head_bf16: bad size rows=%ld n=%d cpc=%d", rows, n, cpc);
     FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_head_bf16: points per frustum (%d) must be a multiple of 32", n);
     FPN_REQUIRE(ldg >= 1024, "v1_seg_head_bf16: leading dimension of global_max (%d) must be >= 1024", ldg);
@@ -792,6 +894,7 @@ int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void 
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh2 = consts[3]; p.sh3 = consts[4]; p.sh4 = consts[5]; p.sh5 = consts[6];
     p.point_feat = reinterpret_cast<bf16x8 *>(point_feat); p.gmax = global_max; p.ldg = ldg;
+    p.copy_vecs = copy_vecs;
     if (groups_per_wave(n) == 2)
         hipLaunchKernelGGL(seg_head_bf16_kernel<2>, grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
     else
@@ -800,8 +903,10 @@ int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void 
 }
 
 int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *group_shift, const void *wstream,
-                         const float *const *consts, float *logits, void *stream)
+                         const float *const *consts, long copy_vecs, const int *drop_mask, float *logits, void *stream)
 {
+    FPN_REQUIRE(copy_vecs >= 0, "v1_seg_tail_bf16: negative stream stride");
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(drop_mask) & 15) == 0, "v1_seg_tail_bf16: drop_mask must be 16-byte aligned");
     FPN_REQUIRE(rows >= 0 && n >= 1, "v1_seg_tail_bf16: bad size");
     FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_tail_bf16: points per frustum (%d) must be a multiple of 32", n);
     if (rows == 0) return FPN_OK;
@@ -812,13 +917,16 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh7 = consts[0]; p.sh8 = consts[1]; p.sh9 = consts[2]; p.w10 = consts[3]; p.b10 = consts[4];
     p.logits = logits;
+    p.copy_vecs = copy_vecs;
+    p.drop = reinterpret_cast<const unsigned *>(drop_mask);
     hipLaunchKernelGGL(seg_tail_bf16_kernel, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
     return check_launch("fpn_v1_seg_tail_bf16");
 }
 
 int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const float *delta, const void *wstream,
-                          const float *const *consts, float *feat_max, int ldg, void *stream)
+                          const float *const *consts, long copy_vecs, float *feat_max, int ldg, void *stream)
 {
+    FPN_REQUIRE(copy_vecs >= 0, "v1_obj_chain_bf16: negative stream stride");
     FPN_REQUIRE(rows >= 0 && m >= 1, "v1_obj_chain_bf16: bad size");
     FPN_REQUIRE(m % 32 == 0 && rows % m == 0, "v1_obj_chain_bf16: object points per frustum (%d) must be a multiple of 32", m);
     FPN_REQUIRE(ldg >= (box ? 512 : 256), "v1_obj_chain_bf16: leading dimension of feat_max (%d) too small", ldg);
@@ -832,6 +940,7 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh2 = consts[3]; p.sh3 = consts[4]; p.sh4 = box ? consts[5] : nullptr;
     p.gmax = feat_max; p.ldg = ldg;
+    p.copy_vecs = copy_vecs;
     const int np = groups_per_wave(m);
     const dim3 grid = grid_for(rows, np), block(64 * kWaves);
     hipStream_t st = as_stream(stream);

@@ -15,7 +15,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
     else os.path.join(_HERE, "libfpn_hip.so")
 
 FPN_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class FpnError(RuntimeError):
@@ -56,9 +56,10 @@ SIGNATURES = {
     "fpn_flipout_weights_f32": [_i, _i, _i, _vp, _vp, _i, _l, _vp, _i, _vp, _i, _i, _vp, _vp],
     "fpn_chain_pad_units_bf16": [],
     "fpn_chain_pack_bf16": [_i, _i, _vp, _vp, _vp, _vp],
-    "fpn_v1_seg_head_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "fpn_v1_seg_tail_bf16": [_l, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "fpn_v1_obj_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "fpn_flipout_stream_bf16": [_l, _i, _i, _vp, _vp, _i, _l, _vp, _i, _vp, _i, _vp, _l, _vp],
+    "fpn_v1_seg_head_bf16": [_l, _i, _i, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp],
+    "fpn_v1_seg_tail_bf16": [_l, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp],
+    "fpn_v1_obj_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _i, _vp],
     "fpn_sa_chain_bf16": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_fp_head_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_fp_head_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -53,7 +53,12 @@ def unpack_keep_bits(bits):
 class BayesPlan:
     """S Monte-Carlo forward passes of the Flipout network."""
 
-    def __init__(self, store, pc_channels=3, chunk_frustums=None, mc_dropout=False, chain=True):
+    def __init__(self, store, pc_channels=3, chunk_frustums=None, mc_dropout=False, chain=True, precision="fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+        if precision == "bf16" and not chain:
+            raise ValueError("bf16 exists for the layer-chain kernels only")
+        self.precision = precision
         self.store = store
         self.pc_channels = pc_channels
         self.chunk_frustums = chunk_frustums
@@ -207,44 +212,76 @@ class BayesPlan:
             return ops.shared_mlp_flipout(x, st[scope + "/weights"], dw, x.shape[0] // samples, si, so, rpg,
                                           scale=None, shift=st[scope + "/biases"], relu=relu)
 
+        bf16 = self.precision == "bf16"
+
+        def streams(scopes, first=None):           # bf16: per-copy weight streams of a kernel
+            layers = [] if first is None else [first]
+            for k in scopes:
+                dw, si, so = nz[k]
+                layers.append((st[k + "/weights"], dw, si, so))
+            return ops.flipout_streams_bf16(b, layers)
+
+        def obj_chain(scopes, box, delta, out):
+            if bf16:
+                ws, cv = streams(scopes[1:])
+                ct = [self._eff(scopes[0], nz, 0), self._one(128)] + [st[k + "/biases"] for k in scopes]
+                ops.v1_obj_chain_bf16(obj2d, m, box, delta, ws, ops.pointer_table(ct), out, copy_vecs=cv)
+            else:
+                t = self._chain_tensors(scopes, nz, (0,) + (1,) * (len(scopes) - 1))
+                ops.v1_obj_chain(obj2d, m, box, delta, ops.pointer_table(t), out, per_frustum=True)
+
         # segmentation net (FPointNet_Bayes.py:71-96): conv1..conv5 + max-pool, then
         # conv6..conv10 with the frustum-constant part of conv6 as a per-frustum shift
-        head = self._chain_tensors(("conv1", "conv2", "conv3", "conv4", "conv5"), nz, (0, 1, 1, 1, 1))
         gcat = torch.zeros((b, 1024 + 3), dtype=torch.float32, device=dev)
         gcat[:, 1024:] = one_hot
-        point_feat = torch.empty((b * n, 64), dtype=torch.float32, device=dev)
-        ops.v1_seg_head(pc.reshape(b * n, c), n, ops.pointer_table(head), point_feat, gcat, per_frustum=True)
+        point_feat = torch.empty((b * n, 64), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        if bf16:
+            ws, cv = streams(("conv2", "conv3", "conv4", "conv5"))
+            head = [self._eff("conv1", nz, 0), self._one(64)] + \
+                [st[k + "/biases"] for k in ("conv1", "conv2", "conv3", "conv4", "conv5")]
+            ops.v1_seg_head_bf16(pc.reshape(b * n, c), n, ws, ops.pointer_table(head), point_feat, gcat, copy_vecs=cv)
+            del ws
+        else:
+            head = self._chain_tensors(("conv1", "conv2", "conv3", "conv4", "conv5"), nz, (0, 1, 1, 1, 1))
+            ops.v1_seg_head(pc.reshape(b * n, c), n, ops.pointer_table(head), point_feat, gcat, per_frustum=True)
         dw6, si6, so6 = nz["conv6"]
         w6 = st["conv6/weights"]
         gshift = ops.shared_mlp_flipout(gcat, w6[64:].contiguous(), dw6[:, 64:].contiguous(), b // samples,
                                         si6[:, 64:].contiguous(), so6, 1, scale=None, shift=st["conv6/biases"],
                                         relu=False)
-        tail = [self._eff("conv6", nz, 1, rows=64), self._one(512)] + \
-            self._chain_tensors(("conv7", "conv8", "conv9"), nz, (1, 2, 2)) + \
-            [self._eff("conv10", nz, 0), st["conv10/biases"]]
         logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
-        ops.v1_seg_tail(point_feat, n, gshift, ops.pointer_table(tail), logits, per_frustum=True,
-                        drop_mask=drop_mask)
+        if bf16:
+            ws, cv = streams(("conv7", "conv8", "conv9"),
+                             first=(w6[:64], dw6[:, :64], si6[:, :64].contiguous(), so6))
+            tail = [st[k + "/biases"] for k in ("conv7", "conv8", "conv9")] + \
+                [self._eff("conv10", nz, 0), st["conv10/biases"]]
+            ops.v1_seg_tail_bf16(point_feat, n, gshift, ws, ops.pointer_table(tail), logits, copy_vecs=cv,
+                                 drop_mask=drop_mask)
+            del ws
+        else:
+            tail = [self._eff("conv6", nz, 1, rows=64), self._one(512)] + \
+                self._chain_tensors(("conv7", "conv8", "conv9"), nz, (1, 2, 2)) + \
+                [self._eff("conv10", nz, 0), st["conv10/biases"]]
+            ops.v1_seg_tail(point_feat, n, gshift, ops.pointer_table(tail), logits, per_frustum=True,
+                            drop_mask=drop_mask)
         del point_feat, head, tail
 
         mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
         obj2d = obj.reshape(b * m, 3)
 
         # T-Net (FPointNet_Bayes.py:120-137)
-        tnet = self._chain_tensors(("conv-reg1-stage1", "conv-reg2-stage1", "conv-reg3-stage1"), nz, (0, 1, 1))
         tcat = torch.zeros((b, 256 + 3), dtype=torch.float32, device=dev)
         tcat[:, 256:] = one_hot
-        ops.v1_obj_chain(obj2d, m, False, None, ops.pointer_table(tnet), tcat, per_frustum=True)
+        obj_chain(("conv-reg1-stage1", "conv-reg2-stage1", "conv-reg3-stage1"), False, None, tcat)
         t = conv(tcat, "fc1-stage1", 1)
         t = conv(t, "fc2-stage1", 1)
         center_delta = self._plain(t, "fc3-stage1")
         stage1_center = center_delta + mean
 
         # box net (FPointNet_Bayes.py:99-117); the kernel subtracts center_delta on load
-        box = self._chain_tensors(("conv-reg1", "conv-reg2", "conv-reg3", "conv-reg4"), nz, (0, 1, 1, 1))
         bcat = torch.zeros((b, 512 + 3), dtype=torch.float32, device=dev)
         bcat[:, 512:] = one_hot
-        ops.v1_obj_chain(obj2d, m, True, center_delta, ops.pointer_table(box), bcat, per_frustum=True)
+        obj_chain(("conv-reg1", "conv-reg2", "conv-reg3", "conv-reg4"), True, center_delta, bcat)
         t = conv(bcat, "fc1", 1)
         t = conv(t, "fc2", 1)
         output = self._plain(t, "fc3")

@@ -217,35 +217,66 @@ def chain_stream_bf16(layers):
     return out
 
 
-def v1_seg_head_bf16(pc2d, n, wstream, consts, point_feat, global_max):
-    """fpn_v1_seg_head_bf16: as v1_seg_head; point_feat (rows,64) bfloat16."""
+def flipout_streams_bf16(copies, layers):
+    """Per-copy weight streams of a bf16 chain kernel under Flipout: `layers` is the
+    list of (w_mean (cin,cout), w_delta (S,cin,cout), sign_in (copies,>=cin), sign_out
+    (copies,cout)) in the order the kernel runs them (fpn_flipout_stream_bf16 per layer).
+    Returns (stream tensor, copy_vecs)."""
+    lib = _lib.load()
+    dev = layers[0][0].device
+    per = sum(l[0].shape[0] * l[0].shape[1] for l in layers)
+    pad = lib.fpn_chain_pad_units_bf16() * 2048
+    out = torch.empty(copies * per + pad, dtype=torch.bfloat16, device=dev)
+    out[copies * per:].zero_()
+    off = 0
+    with torch.cuda.device(dev):
+        for w, dw, si, so in layers:
+            cin, cout = w.shape
+            s = dw.shape[0]
+            if dw.dim() != 3 or copies % s != 0 or dw.stride(2) != 1 or dw.stride(1) != cout:
+                raise ValueError("w_delta must be (samples, cin, cout) with dense matrices and samples dividing %d" % copies)
+            _lib.check(lib.fpn_flipout_stream_bf16(copies, cin, cout, _lib.ptr(w), _lib.ptr(dw), copies // s,
+                                                   dw.stride(0) if s > 1 else 0, _lib.ptr(si), _ld(si), _lib.ptr(so),
+                                                   _ld(so), ctypes.c_void_p(out.data_ptr() + 2 * off), per // 8,
+                                                   _lib.stream_of(w)))
+            off += cin * cout
+    return out, per // 8
+
+
+def v1_seg_head_bf16(pc2d, n, wstream, consts, point_feat, global_max, copy_vecs=0):
+    """fpn_v1_seg_head_bf16: as v1_seg_head; point_feat (rows,64) bfloat16; copy_vecs > 0:
+    one weight stream per frustum (flipout_streams_bf16)."""
     rows, cpc = pc2d.shape
     obs = launch_observer
     tok = obs.begin("v1_seg_head_bf16", rows, 0, 0, macs=rows * (cpc * 64 + 64 * 64 * 2 + 64 * 128 + 128 * 1024)) \
         if obs is not None else None
     with torch.cuda.device(pc2d.device):
         _lib.check(_lib.load().fpn_v1_seg_head_bf16(rows, int(n), cpc, _lib.ptr(pc2d), _lib.ptr(wstream), consts,
-                                                    _lib.ptr(point_feat), _lib.ptr(global_max), _ld(global_max),
+                                                    int(copy_vecs), _lib.ptr(point_feat), _lib.ptr(global_max),
+                                                    _ld(global_max),
                                                     _lib.stream_of(pc2d)))
     if obs is not None:
         obs.end(tok)
 
 
-def v1_seg_tail_bf16(point_feat, n, gbias, wstream, consts, logits):
+def v1_seg_tail_bf16(point_feat, n, gbias, wstream, consts, logits, copy_vecs=0, drop_mask=None):
     """fpn_v1_seg_tail_bf16: as v1_seg_tail on the bfloat16 point_feat of the bf16 head."""
     rows = point_feat.shape[0]
+    if drop_mask is not None and (drop_mask.dtype != torch.int32 or tuple(drop_mask.shape) != (rows, 4)
+                                  or not drop_mask.is_contiguous()):
+        raise ValueError("drop_mask must be a contiguous (rows,4) int32 tensor")
     obs = launch_observer
     tok = obs.begin("v1_seg_tail_bf16", rows, 0, 0, macs=rows * (64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2)) \
         if obs is not None else None
     with torch.cuda.device(point_feat.device):
         _lib.check(_lib.load().fpn_v1_seg_tail_bf16(rows, int(n), _lib.ptr(point_feat), _lib.ptr(gbias),
-                                                    _lib.ptr(wstream), consts, _lib.ptr(logits),
-                                                    _lib.stream_of(point_feat)))
+                                                    _lib.ptr(wstream), consts, int(copy_vecs), _lib.ptr(drop_mask),
+                                                    _lib.ptr(logits), _lib.stream_of(point_feat)))
     if obs is not None:
         obs.end(tok)
 
 
-def v1_obj_chain_bf16(obj2d, m, box, delta, wstream, consts, feat_max):
+def v1_obj_chain_bf16(obj2d, m, box, delta, wstream, consts, feat_max, copy_vecs=0):
     """fpn_v1_obj_chain_bf16: as v1_obj_chain."""
     rows = obj2d.shape[0]
     macs = 3 * 128 + 128 * 128 + 128 * 256 + (256 * 512 if box else 0)
@@ -254,7 +285,8 @@ def v1_obj_chain_bf16(obj2d, m, box, delta, wstream, consts, feat_max):
         if obs is not None else None
     with torch.cuda.device(obj2d.device):
         _lib.check(_lib.load().fpn_v1_obj_chain_bf16(rows, int(m), int(bool(box)), _lib.ptr(obj2d), _lib.ptr(delta),
-                                                     _lib.ptr(wstream), consts, _lib.ptr(feat_max), _ld(feat_max),
+                                                     _lib.ptr(wstream), consts, int(copy_vecs), _lib.ptr(feat_max),
+                                                     _ld(feat_max),
                                                      _lib.stream_of(obj2d)))
     if obs is not None:
         obs.end(tok)

@@ -229,15 +229,18 @@ def side_config(args):
         pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
         st = variables.VariableStore(dev, seed=1)
         bayes.init_variables(st, 3)
-        bp = bayes.BayesPlan(st, 3, mc_dropout=args.mc_dropout)
+        bp = bayes.BayesPlan(st, 3, mc_dropout=args.mc_dropout, precision="bf16" if args.dtype == "bf16" else "fp32")
         gen = torch.Generator(device=dev)
         gen.manual_seed(7 + rank)
 
         def step():
             ep = bp.forward(pc, one_hot, args.samples, generator=gen)
             return uncertainty.mc_statistics(ep["box_output"], ep["stage1_center"])
-        label = "Flipout Frustum PointNet v1, %d Monte-Carlo samples x %d frustums x %d pts per GPU, fp32, " \
+        label = "Flipout Frustum PointNet v1, %d Monte-Carlo samples x %d frustums x %d pts per GPU, %s, " \
                 "ensemble statistics on device%s" % (args.samples, b_local, points,
+                                                     "bf16 MFMA in the convolution stacks (fp32 first layers, "
+                                                     "maxima, head and fully connected layers)"
+                                                     if args.dtype == "bf16" else "fp32",
                                                      ", Monte-Carlo dropout before the head" if args.mc_dropout else "")
         metric = "frustums/sec (node) FPointNet Bayes S=%d N=%d" % (args.samples, points)
     gathered = None
@@ -280,7 +283,7 @@ def side_config(args):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None,
-                          "dtype": "bf16" if (args.dtype == "bf16" and args.config == "v2") else "f32",
+                          "dtype": args.dtype,
                           "data": "synthetic",
                           "config": {"workload": label, "frustums_per_gpu": b_local, "points": points}}))
     if world > 1:

@@ -392,22 +392,35 @@ int fpn_fp_head_chain_f32(long rows, int ca, int cb, const float *xa, const floa
 int fpn_chain_pad_units_bf16(void);
 int fpn_chain_pack_bf16(int cin, int cout, const float *w, const float *scale, void *units,
                         void *stream);
+/*
+ * Flipout (models/FPointNet_Bayes.py:54-68) on these chains: copy_vecs > 0 gives every
+ * frustum its OWN stream, copy_vecs 16-byte vectors after the previous frustum's
+ * (>= the stream's own length; padding only after the last copy), written layer by
+ * layer by fpn_flipout_stream_bf16 - arguments as fpn_flipout_weights_f32, `units` =
+ * where the layer starts inside the first copy's stream - and its own fp32 first-layer
+ * (and conv10) matrix, (frustum, k, cout) back to back (fpn_flipout_weights_f32,
+ * layout 0).  copy_vecs == 0: one stream for all frustums.
+ */
+int fpn_flipout_stream_bf16(long copies, int cin, int cout, const float *w_mean, const float *w_delta,
+                            int frustums_per_delta, long delta_stride, const float *sign_in, int ld_in,
+                            const float *sign_out, int ld_out, void *units, long copy_vecs,
+                            void *stream);
 /* stream: conv2, conv3, conv4, conv5; consts {w1 (cpc,64), scale1, shift1, shift2..shift5};
  * point_feat (rows,64) bf16 in an internal operand order, only meaningful to
  * fpn_v1_seg_tail_bf16; global_max as in fpn_v1_seg_head_f32. */
 int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void *wstream,
-                         const float *const *consts, void *point_feat, float *global_max, int ldg,
-                         void *stream);
+                         const float *const *consts, long copy_vecs, void *point_feat,
+                         float *global_max, int ldg, void *stream);
 /* stream: conv6 rows 0..63, conv7, conv8, conv9; consts {shift7, shift8, shift9, w10
- * (128,2), bias10}; group_shift as in fpn_v1_seg_tail_f32. */
+ * (128,2), bias10}; group_shift and drop_mask as in fpn_v1_seg_tail_f32. */
 int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *group_shift,
-                         const void *wstream, const float *const *consts, float *logits,
-                         void *stream);
+                         const void *wstream, const float *const *consts, long copy_vecs,
+                         const int *drop_mask, float *logits, void *stream);
 /* stream: layer 2, layer 3 (, layer 4 when box != 0); consts {w1 (3,128), scale1,
  * shift1, shift2, shift3 (, shift4)}. */
 int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const float *delta,
-                          const void *wstream, const float *const *consts, float *feat_max,
-                          int ldg, void *stream);
+                          const void *wstream, const float *const *consts, long copy_vecs,
+                          float *feat_max, int ldg, void *stream);
 /* Shapes and padding rules of fpn_sa_chain_f32; c3_valid % 64 == 0.
  *   cf < 32 : stream: layer 2, layer 3; consts {w1 (3+cf,c1) fp32, scale1, shift1,
  *             shift2, shift3};

@@ -156,3 +156,72 @@ def test_bf16_set_abstraction_within_stated_bound(device):
         assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
         err = scaled_err(outs["bf16"], outs["fp32"])
         assert 1e-6 < err <= BF16_RTOL, (kind, args[0], err)
+
+
+def test_bf16_flipout_streams_exact(device):
+    """fpn_flipout_stream_bf16: every copy's units equal the packed stream of that copy's
+    effective weights W_mean + diag(s_in) dW diag(s_out) (signs are +-1: one rounding),
+    several layers back to back, several samples per call, a column slice as sign_in."""
+    from fpn import ops
+    rng = np.random.RandomState(7)
+    S, per = 2, 3
+    copies = S * per
+    shapes = ((64, 512), (512, 256), (32, 64))
+    layers, effs = [], []
+    for cin, cout in shapes:
+        w = rng.standard_normal((cin, cout)).astype(np.float32)
+        dw = rng.standard_normal((S, cin, cout)).astype(np.float32)
+        si_wide = rng.choice([-1.0, 1.0], (copies, cin + 5)).astype(np.float32)
+        so = rng.choice([-1.0, 1.0], (copies, cout)).astype(np.float32)
+        layers.append((dev(w, device), dev(dw, device), dev(si_wide, device)[:, :cin], dev(so, device)))
+        effs.append(w[None] + si_wide[:, :cin, None] * np.repeat(dw, per, 0) * so[:, None, :])
+    got, copy_vecs = ops.flipout_streams_bf16(copies, layers)
+    total = sum(a * b for a, b in shapes)
+    assert copy_vecs * 8 == total
+    for f in range(copies):
+        want = ops.chain_stream_bf16([(dev(e[f], device), None) for e in effs])[:total]
+        assert torch.equal(got[f * total:(f + 1) * total].view(torch.int16), want.view(torch.int16)), f
+
+
+@pytest.mark.parametrize("B,N,dropout", [(4, 256, False), (13, 96, True), (16, 1024, False)])
+def test_bf16_bayes_within_stated_bound(device, B, N, dropout):
+    """The Flipout network on the bf16 chains (per-copy weight streams) against the
+    float64 textbook Flipout oracle under BF16_RTOL; with Monte-Carlo dropout in the tail
+    kernel; 13 x 96: frustum boundaries inside workgroups, 16 x 1024: XCD-grouped order."""
+    from fpn import bayes, synthetic, variables
+    from oracle import bayes_numpy as BN
+    st = variables.VariableStore(device, seed=4)
+    bp = bayes.BayesPlan(st, 3, mc_dropout=dropout, precision="bf16")
+    for k in list(st.keys()):
+        if k.endswith("/biases"):
+            st[k] = torch.randn(st[k].shape) * 0.1
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=B)
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    S = 2
+    noise = bp.sample_noise(S, B, g, N)
+    ep = bp.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+    keep = None
+    if dropout:
+        bits = noise["dropout"].cpu().numpy()
+        keep = ((bits[..., None] >> np.arange(32)) & 1).reshape(S, B, N, 128).astype(bool)
+    params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
+    worst = {}
+    for s in range(S):
+        nz = {k: ((torch.nn.functional.softplus(st[k + "/rho"]) + np.finfo(np.float32).eps) * v[0][s]).cpu().numpy()
+              for k, v in noise.items() if k != "dropout"}
+        nz = {k: (nz[k].astype(np.float64), noise[k][1][s].cpu().numpy().astype(np.float64),
+                  noise[k][2][s].cpu().numpy().astype(np.float64)) for k in nz}
+        kw = {} if keep is None else {"dropout_keep": keep[s]}
+        want = BN.forward_sample(pc.astype(np.float64), oh.astype(np.float64), params, nz, **kw)
+        worst["mask_logits"] = max(worst.get("mask_logits", 0),
+                                   scaled_err(ep["mask_logits"][s].cpu().numpy(), want["mask_logits"]))
+        mask = ep["mask"][s].cpu().numpy()
+        want = BN.forward_sample(pc.astype(np.float64), oh.astype(np.float64), params, nz, mask_override=mask, **kw)
+        np.testing.assert_array_equal(ep["object_point_indices"][s].cpu().numpy(), want["object_point_indices"])
+        for k in ("center_delta", "stage1_center", "box_output", "center"):
+            worst[k] = max(worst.get(k, 0), scaled_err(ep[k][s].cpu().numpy(), want[k]))
+    print("bf16 Flipout scaled errors:", {k: "%.2e" % v for k, v in worst.items()})
+    assert max(worst.values()) <= BF16_RTOL, worst
+    assert worst["mask_logits"] > 1e-5, "suspiciously exact: is the bf16 path running?"
+    assert not torch.equal(ep["box_output"][0], ep["box_output"][1])
