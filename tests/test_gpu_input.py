@@ -46,3 +46,33 @@ def test_dataset_and_record_batches_through_get_model(device, tmp_path):
         want = V.get_model(pc.cpu().numpy(), one_hot.cpu().numpy(), st3.numpy())
         close(ep["mask_logits"].cpu().numpy(), want["mask_logits"])
     assert sizes == [4, 2]
+
+
+def test_detection_driver_on_the_device_model(device, tmp_path):
+    """scripts/test.py's loop with the real detection model: record file -> batches ->
+    det_model.predict -> result lists; the lists equal the oracle's network outputs
+    post-processed by the same formulas."""
+    from fpn import inference, variables
+    from fpn.models import FPointNet_Keras as K
+    from test_detection_driver import write_test_records
+    path = str(tmp_path / "test.tfrec")
+    rows = write_test_records(path, 8, seed=3)
+    st = variables.VariableStore(device, seed=5)
+    with variables.use_store(st):
+        _, det = K.Frustum_Pointnet_Model(batch_size=4)
+        lists = inference.test(det, inference.make_test_iterator(path, 4), str(tmp_path / "det.pkl"),
+                               result_dir=str(tmp_path / "res"), csv_path=None)
+    assert len(lists["ps"]) == 8
+    pc = np.stack([r[0] for r in rows])
+    oh = np.stack([r[1] for r in rows]).astype(np.float32)
+    want = V.get_model(pc, oh, st.numpy(), bn=False)
+    seg, c, hc, hr, sc, sr, s = inference.postprocess(want["mask_logits"], want["center"], want["heading_scores"],
+                                                      want["heading_residuals"], want["size_scores"],
+                                                      want["size_residuals"])
+    assert (np.stack(lists["segp"]) != seg).mean() < 0.01          # flips only where the two logits tie
+    close(np.stack(lists["center"]), c)
+    np.testing.assert_array_equal(np.asarray(lists["heading_cls"]), hc)
+    np.testing.assert_array_equal(np.asarray(lists["size_cls"]), sc)
+    close(np.asarray(lists["heading_res"]), hr)
+    close(np.stack(lists["size_res"]), sr)
+    close(np.asarray(lists["score"]), s)
