@@ -69,3 +69,105 @@ def gather_ragged(records, total, group=None):
         lo, hi = shard_range(total, r, world)
         keep.append(full[r * per:r * per + (hi - lo)])
     return torch.cat(keep, dim=0)
+
+
+def _as_host_tensor(a):
+    if isinstance(a, torch.Tensor):
+        if a.device.type != "cpu":
+            raise ValueError("run_streamed takes HOST arrays (it owns the copies to the device)")
+        return a.contiguous()
+    return torch.from_numpy(a).contiguous()       # shares numpy's memory
+
+
+def run_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False):
+    """A scene set larger than one batch: walk this rank's frustums in chunks of `chunk`
+    with the next chunk's host -> device copy overlapped with the current chunk's compute.
+
+    point_cloud (B,N,C) and one_hot (B,3): float32 HOST arrays or tensors; forward(pc, oh)
+    -> end_points on `device`; returns the (B, RECORD [+2N]) result records on `device`.
+
+    Two device slots and two pinned staging slots; per chunk: the host copies its rows into
+    the pinned slot (skipped when the source is pinned already), a COPY stream moves them
+    to the device slot, the compute stream waits for that copy only, and the copy stream
+    waits for the slot's previous compute before it overwrites the slot.  Compute never
+    waits for the host except through a full staging pipeline."""
+    pc_h, oh_h = _as_host_tensor(point_cloud), _as_host_tensor(one_hot)
+    if pc_h.dtype != torch.float32 or oh_h.dtype != torch.float32 or pc_h.dim() != 3 or oh_h.dim() != 2 \
+            or oh_h.shape[0] != pc_h.shape[0]:
+        raise ValueError("point_cloud must be (B,N,C) float32 and one_hot (B,K) float32 with the same B")
+    if chunk < 1:
+        raise ValueError("chunk must be positive")
+    total, n, c = pc_h.shape
+    device = torch.device(device)
+    width = RECORD + (2 * n if with_logits else 0)
+    records = torch.empty((total, width), dtype=torch.float32, device=device)
+    if total == 0:
+        return records
+    if device.type != "cuda":
+        for lo in range(0, total, chunk):
+            hi = min(total, lo + chunk)
+            records[lo:hi] = pack_results(forward(pc_h[lo:hi].to(device), oh_h[lo:hi].to(device)), with_logits)
+        return records
+
+    rows = min(chunk, total)
+    pinned_src = pc_h.is_pinned() and oh_h.is_pinned()
+    with torch.cuda.device(device):
+        main = torch.cuda.current_stream()
+        copy = torch.cuda.Stream()
+        dev_pc = [torch.empty((rows, n, c), dtype=torch.float32, device=device) for _ in range(2)]
+        dev_oh = [torch.empty((rows, oh_h.shape[1]), dtype=torch.float32, device=device) for _ in range(2)]
+        stage = None if pinned_src else [(torch.empty((rows, n, c), dtype=torch.float32).pin_memory(),
+                                          torch.empty((rows, oh_h.shape[1]), dtype=torch.float32).pin_memory())
+                                         for _ in range(2)]
+        copied = [torch.cuda.Event() for _ in range(2)]      # slot's H2D done (copy stream)
+        consumed = [torch.cuda.Event() for _ in range(2)]    # slot's compute done (compute stream)
+        used = [False, False]
+
+        def enqueue_copy(i):
+            lo = i * chunk
+            hi = min(total, lo + chunk)
+            slot, k = i % 2, hi - lo
+            if used[slot]:
+                copy.wait_event(consumed[slot])      # device slot: its previous chunk has been computed
+            if stage is not None:
+                if used[slot]:
+                    copied[slot].synchronize()       # staging slot: its previous chunk has left the host
+                stage[slot][0][:k].copy_(pc_h[lo:hi])
+                stage[slot][1][:k].copy_(oh_h[lo:hi])
+                src_pc, src_oh = stage[slot][0][:k], stage[slot][1][:k]
+            else:
+                src_pc, src_oh = pc_h[lo:hi], oh_h[lo:hi]
+            with torch.cuda.stream(copy):
+                dev_pc[slot][:k].copy_(src_pc, non_blocking=True)
+                dev_oh[slot][:k].copy_(src_oh, non_blocking=True)
+                copied[slot].record(copy)
+            used[slot] = True
+
+        nchunks = (total + chunk - 1) // chunk
+        enqueue_copy(0)
+        for i in range(nchunks):
+            if i + 1 < nchunks:
+                enqueue_copy(i + 1)
+            lo = i * chunk
+            hi = min(total, lo + chunk)
+            slot, k = i % 2, hi - lo
+            main.wait_event(copied[slot])
+            records[lo:hi] = pack_results(forward(dev_pc[slot][:k], dev_oh[slot][:k]), with_logits)
+            consumed[slot].record(main)
+        # the slots must outlive the queued work that reads them
+        main.synchronize()
+    return records
+
+
+def run_sharded_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False, group=None):
+    """The whole scene set on every rank's host (or at least this rank's block of it):
+    rank r streams frustums shard_range(B, r, W) through `forward` and the records of all
+    ranks are gathered once at the end -> (B, RECORD [+2N]) on every rank."""
+    total = point_cloud.shape[0]
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_range(total, rank, world)
+    rec = run_streamed(forward, point_cloud[lo:hi], one_hot[lo:hi], chunk, device, with_logits)
+    return gather_ragged(rec, total, group)

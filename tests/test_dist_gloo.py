@@ -61,3 +61,46 @@ def test_two_rank_gather_even(tmp_path):
 
 def test_two_rank_gather_ragged(tmp_path):
     _run(7, tmp_path, 29512)
+
+
+def _toy_forward(pc, oh):
+    """Per-frustum stand-in for the network: every output row depends on its own frustum only."""
+    s = pc.sum(dim=(1, 2))
+    return {"box_output": s[:, None] + torch.arange(59, dtype=torch.float32)[None] + oh[:, :1],
+            "stage1_center": pc[:, 0, :3] * 2, "mask_xyz_mean": pc.mean(1)[:, :3],
+            "mask_logits": pc[:, :, :2].contiguous()}
+
+
+def _stream_worker(rank, world, port, total, chunk, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "3d-object-detection_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fpn import dist as fdist
+    rng = np.random.RandomState(0)                      # the same scene set on every rank
+    pc = rng.standard_normal((total, 8, 4)).astype(np.float32)
+    oh = np.eye(3, dtype=np.float32)[rng.randint(0, 3, total)]
+    full = fdist.run_sharded_streamed(_toy_forward, pc, oh, chunk, "cpu", with_logits=True)
+    torch.save(full, os.path.join(out_dir, "stream%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_streamed_scene_set(tmp_path):
+    """Scene set of 11 frustums, 2 ranks, chunks of 3: every rank streams its block and all
+    ranks end with the records of the whole set in frustum order."""
+    total, chunk = 11, 3
+    mp.spawn(_stream_worker, args=(2, 29513, total, chunk, str(tmp_path)), nprocs=2, join=True)
+    from fpn import dist as fdist
+    rng = np.random.RandomState(0)
+    pc = torch.from_numpy(rng.standard_normal((total, 8, 4)).astype(np.float32))
+    oh = torch.from_numpy(np.eye(3, dtype=np.float32)[rng.randint(0, 3, total)])
+    want = fdist.pack_results(_toy_forward(pc, oh), with_logits=True)
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), "stream%d.pt" % r))
+        assert torch.equal(got, want)
+    # single process, no process group: the same call degenerates to a plain chunked loop
+    assert torch.equal(fdist.run_sharded_streamed(_toy_forward, pc.numpy(), oh.numpy(), 4, "cpu", True), want)
+    assert fdist.run_streamed(_toy_forward, pc[:0], oh[:0], 4, "cpu").shape == (0, fdist.RECORD)

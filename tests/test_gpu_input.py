@@ -76,3 +76,26 @@ def test_detection_driver_on_the_device_model(device, tmp_path):
     close(np.asarray(lists["heading_res"]), hr)
     close(np.stack(lists["size_res"]), sr)
     close(np.asarray(lists["score"]), s)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_streamed_scene_set_equals_one_batch(device, pinned):
+    """fpn.dist.run_streamed: chunks with copies overlapped on a second stream give the
+    records of the one-batch forward bit for bit (frustums are independent), ragged last
+    chunk, more chunks than slots, pinned and pageable sources."""
+    from fpn import dist as fdist
+    from fpn import plan, synthetic, variables
+    st = variables.VariableStore(device, seed=1)
+    plan.init_variables(st, 4, True)
+    st.randomize_batch_norm(2)
+    net = plan.V1Plan(st, 4, True)
+    pc, oh = synthetic.make_frustums(11, 256, 4, seed=8)
+    want = fdist.pack_results(net.forward(torch.from_numpy(pc).to(device), torch.from_numpy(oh).to(device)), True)
+    src_pc, src_oh = torch.from_numpy(pc), torch.from_numpy(oh)
+    if pinned:
+        src_pc, src_oh = src_pc.pin_memory(), src_oh.pin_memory()
+    for chunk in (3, 4, 16):
+        got = fdist.run_streamed(net.forward, src_pc, src_oh, chunk, device, with_logits=True)
+        assert torch.equal(got, want), chunk
+    with pytest.raises(ValueError):
+        fdist.run_streamed(net.forward, torch.from_numpy(pc).to(device), src_oh, 4, device)
