@@ -783,30 +783,43 @@ __global__ void pack_units_kernel(int cin, int cout, const float *__restrict__ w
 // Flipout: the units of one layer for every frustum copy f,
 //   W_eff[f] = W_mean + diag(sign_in[f]) . dW[f / frustums_per_delta] . diag(sign_out[f]),
 // converted to bf16 in the element order of pack_units_kernel.  One thread writes one
-// 16-byte vector; blockIdx.y = copy.
-__global__ __launch_bounds__(256) void flipout_units_kernel(int cin, int cout, const float *__restrict__ w_mean,
+// 16-byte vector per copy for kFlipCopies consecutive copies (blockIdx.y): mean and
+// perturbation are read once per group, only the signs differ from copy to copy.
+constexpr int kFlipCopies = 8;
+
+__global__ __launch_bounds__(256) void flipout_units_kernel(long copies, int cin, int cout, const float *__restrict__ w_mean,
                                                             const float *__restrict__ w_delta, int frustums_per_delta,
                                                             long delta_stride, const float *__restrict__ sign_in,
                                                             int ld_in, const float *__restrict__ sign_out, int ld_out,
                                                             bf16x8 *__restrict__ dst, long copy_vecs, long copy0)
 {
-    const long f = copy0 + blockIdx.y;
+    const long f0 = copy0 + (long)blockIdx.y * kFlipCopies;
+    const int nf = (int)min((long)kFlipCopies, copies - f0);
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= cin * cout / 8) return;
     const int nj = cin / 32;
     const int l = v & 63, s = (v >> 6) & 1, u = (v >> 7) & 1, unit = v >> 8;
     const int tp = unit / nj, j = unit % nj;
     const int col = 32 * (2 * tp + u) + (l & 31), k0 = 32 * j + 16 * s + 4 * (l >> 5);
-    const float *dw = w_delta + (f / frustums_per_delta) * delta_stride;
-    const float so = sign_out[f * ld_out + col];
-    const float *si = sign_in + f * ld_in;
-    bf16x8 o;
+    float m[8], d[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = k0 + 8 * (e >> 2) + (e & 3);
-        o[e] = (__bf16)fmaf(dw[(long)k * cout + col], si[k] * so, w_mean[(long)k * cout + col]);
+    for (int e = 0; e < 8; ++e) m[e] = w_mean[(long)(k0 + 8 * (e >> 2) + (e & 3)) * cout + col];
+    long sample = -1;
+    for (int c = 0; c < nf; ++c) {
+        const long f = f0 + c;
+        if (f / frustums_per_delta != sample) {
+            sample = f / frustums_per_delta;
+            const float *dw = w_delta + sample * delta_stride;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = dw[(long)(k0 + 8 * (e >> 2) + (e & 3)) * cout + col];
+        }
+        const float so = sign_out[f * ld_out + col];
+        const float *si = sign_in + f * ld_in + k0;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaf(d[e], si[8 * (e >> 2) + (e & 3)] * so, m[e]);
+        dst[f * copy_vecs + v] = o;
     }
-    dst[f * copy_vecs + v] = o;
 }
 
 inline dim3 grid_for(long rows, int np)
@@ -869,9 +882,10 @@ int fpn_flipout_stream_bf16(long copies, int cin, int cout, const float *w_mean,
     if (copies == 0) return FPN_OK;
     FPN_REQUIRE(w_mean && w_delta && sign_in && sign_out && units, "flipout_stream_bf16: null pointer");
     const unsigned gx = (unsigned)((cin * cout / 8 + 255) / 256);
-    for (long c0 = 0; c0 < copies; c0 += 65535) {
-        const unsigned gy = (unsigned)std::min<long>(65535, copies - c0);
-        hipLaunchKernelGGL(flipout_units_kernel, dim3(gx, gy), dim3(256), 0, as_stream(stream), cin, cout, w_mean, w_delta,
+    const long per_launch = 65535L * kFlipCopies;
+    for (long c0 = 0; c0 < copies; c0 += per_launch) {
+        const unsigned gy = (unsigned)((std::min<long>(per_launch, copies - c0) + kFlipCopies - 1) / kFlipCopies);
+        hipLaunchKernelGGL(flipout_units_kernel, dim3(gx, gy), dim3(256), 0, as_stream(stream), copies, cin, cout, w_mean, w_delta,
                            frustums_per_delta, delta_stride, sign_in, ld_in, sign_out, ld_out,
                            reinterpret_cast<bf16x8 *>(units), copy_vecs, c0);
     }

@@ -931,21 +931,34 @@ __global__ void tile_weights_reg_kernel(int cin, int cout, int jmajor, const flo
 // kernel reads: out[f][e] = wm[k][c] + dw[k][c] * sin[f][k] * sout[f][c] with (k, c) the
 // matrix element that lives at position e of `layout` (0 row-major, 1 / 2 the chunked
 // layout of tile_weights_reg_kernel, output-tile / input-tile major).
-__global__ void flipout_weights_kernel(int cin, int cout, int layout, const float *__restrict__ wm,
+// blockIdx.y = a group of kFlipCopies consecutive frustum copies: the mean and the
+// perturbation are read once per group (copies of one Monte-Carlo sample are neighbours)
+// and only the signs differ, so the kernel is write-bound instead of re-reading both
+// matrices through L2 for every copy.
+constexpr int kFlipCopies = 8;
+
+__global__ void flipout_weights_kernel(int b, int cin, int cout, int layout, const float *__restrict__ wm,
                                        const float *__restrict__ dw, const float *__restrict__ sin, int ldi,
                                        const float *__restrict__ sout, int ldo, float *__restrict__ out,
                                        int per_delta, long delta_stride)
 {
     const long total = (long)cin * cout;
-    const long f = blockIdx.y;
-    dw += (f / per_delta) * delta_stride;      // the Monte-Carlo sample this frustum copy belongs to
-    sin += f * ldi;
-    sout += f * ldo;
-    out += f * total;
+    const long f0 = (long)blockIdx.y * kFlipCopies;
+    const int nf = (int)min((long)kFlipCopies, b - f0);
     if (layout == 0) {
         for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < (unsigned)total; e += gridDim.x * blockDim.x) {
             const unsigned k = e / (unsigned)cout, col = e % (unsigned)cout;
-            out[e] = wm[e] + dw[e] * (sin[k] * sout[col]);
+            const float m = wm[e];
+            long sample = -1;
+            float d = 0.f;
+            for (int c = 0; c < nf; ++c) {
+                const long f = f0 + c;
+                if (f / per_delta != sample) {
+                    sample = f / per_delta;
+                    d = dw[sample * delta_stride + e];
+                }
+                out[f * total + e] = m + d * (sin[f * ldi + k] * sout[f * ldo + col]);
+            }
         }
         return;
     }
@@ -956,15 +969,26 @@ __global__ void flipout_weights_kernel(int cin, int cout, int layout, const floa
         const unsigned t = layout == 2 ? chunk % nt : chunk / nj;
         const unsigned j = layout == 2 ? chunk / nt : chunk % nj;
         const unsigned k = 32 * j + 8 * q + 4 * (l >> 5), col = 32 * t + (l & 31);
-        const float so = sout[col];
-        const float4 si = *reinterpret_cast<const float4 *>(sin + k);
         const size_t src = (size_t)k * cout + col;
-        float4 v;
-        v.x = wm[src] + dw[src] * (si.x * so);
-        v.y = wm[src + cout] + dw[src + cout] * (si.y * so);
-        v.z = wm[src + 2 * (size_t)cout] + dw[src + 2 * (size_t)cout] * (si.z * so);
-        v.w = wm[src + 3 * (size_t)cout] + dw[src + 3 * (size_t)cout] * (si.w * so);
-        reinterpret_cast<float4 *>(out)[g] = v;
+        const float m0 = wm[src], m1 = wm[src + cout], m2 = wm[src + 2 * (size_t)cout], m3 = wm[src + 3 * (size_t)cout];
+        long sample = -1;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        for (int c = 0; c < nf; ++c) {
+            const long f = f0 + c;
+            if (f / per_delta != sample) {
+                sample = f / per_delta;
+                const float *d = dw + sample * delta_stride + src;
+                d0 = d[0]; d1 = d[cout]; d2 = d[2 * (size_t)cout]; d3 = d[3 * (size_t)cout];
+            }
+            const float so = sout[f * ldo + col];
+            const float4 si = *reinterpret_cast<const float4 *>(sin + f * ldi + k);
+            float4 v;
+            v.x = m0 + d0 * (si.x * so);
+            v.y = m1 + d1 * (si.y * so);
+            v.z = m2 + d2 * (si.z * so);
+            v.w = m3 + d3 * (si.w * so);
+            reinterpret_cast<float4 *>(out + f * total)[g] = v;
+        }
     }
 }
 
@@ -1011,12 +1035,13 @@ int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const
                 "flipout_weights: the chunked layouts read sign_in and write out in 16-byte groups (ld_in %d)", ld_in);
     FPN_REQUIRE((long)cin * cout < (1L << 31), "flipout_weights: layer too large");
     if (b == 0) return FPN_OK;
-    FPN_REQUIRE(b <= 65535, "flipout_weights: at most 65535 frustums per call (%d)", b);
+    FPN_REQUIRE(b <= 65535 * kFlipCopies, "flipout_weights: at most %d frustums per call (%d)", 65535 * kFlipCopies, b);
     FPN_REQUIRE(w_mean && w_delta && sign_in && sign_out && out, "flipout_weights: null pointer");
     const long total = (long)cin * cout;
-    hipLaunchKernelGGL(flipout_weights_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1024), (unsigned)b), dim3(256),
-                       0, as_stream(stream), cin, cout, layout, w_mean, w_delta, sign_in, ld_in, sign_out, ld_out, out,
-                       frustums_per_delta, delta_stride);
+    hipLaunchKernelGGL(flipout_weights_kernel,
+                       dim3((unsigned)std::min<long>((total + 255) / 256, 1024), (unsigned)((b + kFlipCopies - 1) / kFlipCopies)),
+                       dim3(256), 0, as_stream(stream), b, cin, cout, layout, w_mean, w_delta, sign_in, ld_in, sign_out, ld_out,
+                       out, frustums_per_delta, delta_stride);
     return check_launch("fpn_flipout_weights_f32");
 }
 
