@@ -49,6 +49,39 @@ def test_layer_matches_numpy(device, rows, cin, cout, relu):
     close(got.cpu().numpy(), want, 1e-4)
 
 
+def test_few_row_kernel_equals_tiled_kernel_bit_for_bit(device):
+    """Launches with few rows run one wave per 32 x 32 output tile, larger ones the LDS-tiled
+    workgroups; both accumulate in the same order, so a row's result does not depend on the
+    batch it arrives in (plain layer with a per-group bias, and the two-pass Flipout layer
+    with one sign group per row)."""
+    from fpn import ops
+    rng = np.random.RandomState(12)
+    rows, few, cin, cout = 8192, 77, 515, 512          # 8192 x 512: 4096 tiles of 32 x 32 = tiled path
+    x = dev(rng.standard_normal((rows, cin)).astype(np.float32), device)
+    w = dev((rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32), device)
+    scale = dev(rng.uniform(0.5, 1.5, cout).astype(np.float32), device)
+    shift = dev(rng.standard_normal(cout).astype(np.float32), device)
+    gb = dev(rng.standard_normal((rows, cout)).astype(np.float32), device)
+    big = ops.shared_mlp(x, w, scale, shift, relu=True, group_bias=gb, rows_per_group=1)
+    small = ops.shared_mlp(x[:few].contiguous(), w, scale, shift, relu=True, group_bias=gb[:few].contiguous(),
+                           rows_per_group=1)
+    assert float(big.abs().max()) > 0 and torch.equal(big[:few], small)
+    # a narrow output (fc3's 59 columns) takes the 128 x 64 tiles when the batch is large
+    w59 = w[:, :59].contiguous()
+    big = ops.shared_mlp(torch.cat([x] * 8), w59, None, shift[:59].contiguous(), relu=False)
+    small = ops.shared_mlp(x[:few].contiguous(), w59, None, shift[:59].contiguous(), relu=False)
+    assert torch.equal(big[:few], small)
+    dw = dev((rng.standard_normal((1, cin, cout)) * 0.05).astype(np.float32), device)
+    si = dev(rng.choice([-1.0, 1.0], (rows, cin)).astype(np.float32), device)
+    so = dev(rng.choice([-1.0, 1.0], (rows, cout)).astype(np.float32), device)
+    big = ops.shared_mlp_flipout(x, w, dw, rows, si, so, 1, scale=None, shift=shift, relu=True)
+    small = ops.shared_mlp_flipout(x[:few].contiguous(), w, dw, few, si[:few].contiguous(), so[:few].contiguous(), 1,
+                                   scale=None, shift=shift, relu=True)
+    assert torch.equal(big[:few], small)
+    want = x[:few].double() @ w.double() + ((x[:few] * si[:few]).double() @ dw[0].double()) * so[:few].double() + shift.double()
+    close(small.cpu().numpy(), np.maximum(want.cpu().numpy(), 0), 1e-4)
+
+
 @pytest.mark.parametrize("pool", [32, 64, 128, 256, 1024])
 def test_layer_pool_and_group_bias(device, pool):
     from fpn import ops
