@@ -12,7 +12,8 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python -u bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
 args="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pointset --no-kernel-timer --steps 5 --warmup 2"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o v1 -- python3 $args > $out/stats_run.log 2>&1
+# (40 steps: the first launches after start-up run at ramping clocks and would dominate a short average)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o v1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pointset --no-kernel-timer --steps 40 --warmup 5 > $out/stats_run.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $args > $out/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $args > $out/pmc_write.log 2>&1
 cd $GRAFT_REPO_ROOT
