@@ -246,6 +246,27 @@ __global__ void gather_point_kernel(long total, int n, int m, const float *__res
 }
 
 // ---------------------------------------------------------------------------
+// Grids (blocks of a frustum, frustums): the workgroups of one frustum read the same
+// points, and workgroup ids are handed to the eight XCDs - each with an L2 of its own -
+// in turn, x fastest.  Taken as they come, the blocks of a frustum land on all eight and
+// every L2 fetches the frustum's points for itself (measured on the fused interpolation:
+// 4x the algorithmic read traffic at the memory side).  So launch id i works on logical
+// block (i % 8) * (total / 8) + i / 8: consecutive logical blocks - a frustum's - share
+// an XCD.  (x, y) = the logical block's position in the launch grid.
+// ---------------------------------------------------------------------------
+struct BlockXY {
+    unsigned x, y;
+};
+
+__device__ __forceinline__ BlockXY frustum_major_block()
+{
+    const unsigned long long gx = gridDim.x, total = gx * gridDim.y;
+    unsigned long long i = blockIdx.y * gx + blockIdx.x;
+    if (total % 8 == 0) i = (i % 8) * (total / 8) + i / 8;
+    return BlockXY{(unsigned)(i % gx), (unsigned)(i / gx)};
+}
+
+// ---------------------------------------------------------------------------
 // Ball query.
 //
 // Grid (query blocks, frustums).  A workgroup stages a tile of the frustum's
@@ -273,10 +294,11 @@ __global__ __launch_bounds__(kQbThreads) void query_ball_kernel(
     extern __shared__ float smem[];
     constexpr int W = kQbThreads / kWave;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bi = blockIdx.y;
+    const BlockXY blk = frustum_major_block();
+    const int bi = blk.y;
     const float *data = xyz1 + (size_t)bi * n * 3;
     const float *query = xyz2 + (size_t)bi * m * 3;
-    const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+    const int q0 = blk.x * qpb, q1 = min(m, q0 + qpb);
 
     float *tile = smem;                                       // kQbTile*3 floats
     int *s_cnt = reinterpret_cast<int *>(smem + kQbTile * 3); // qpb
@@ -349,9 +371,10 @@ __global__ __launch_bounds__(kRowThreads) void group_point_kernel(
 {
     constexpr int RPB = kRowThreads / LW;
     const int lx = threadIdx.x % LW, ly = threadIdx.x / LW;
-    for (int bi = blockIdx.y; bi < b; bi += gridDim.y) {
+    const BlockXY blk = frustum_major_block();
+    for (int bi = blk.y; bi < b; bi += gridDim.y) {
         const float *p = points + (size_t)bi * n * c;
-        for (int r = blockIdx.x * RPB + ly; r < rows_per_batch; r += gridDim.x * RPB) {
+        for (int r = blk.x * RPB + ly; r < rows_per_batch; r += gridDim.x * RPB) {
             const size_t row = (size_t)bi * rows_per_batch + r;
             const int ii = idx[row];
             const float *src = p + (size_t)ii * c;
@@ -361,24 +384,61 @@ __global__ __launch_bounds__(kRowThreads) void group_point_kernel(
     }
 }
 
+// the same copy in 16-byte groups (c a multiple of 4, 16-byte aligned arrays): c4 = c / 4
+// groups per row, LW lanes along them
+template <int LW>
+__global__ __launch_bounds__(kRowThreads) void group_point_vec_kernel(
+    int b, int n, int c4, int rows_per_batch, const float4 *__restrict__ points,
+    const int *__restrict__ idx, float4 *__restrict__ out)
+{
+    constexpr int RPB = kRowThreads / LW;
+    const int lx = threadIdx.x % LW, ly = threadIdx.x / LW;
+    const BlockXY blk = frustum_major_block();
+    for (int bi = blk.y; bi < b; bi += gridDim.y) {
+        const float4 *p = points + (size_t)bi * n * c4;
+        for (int r = blk.x * RPB + ly; r < rows_per_batch; r += gridDim.x * RPB) {
+            const size_t row = (size_t)bi * rows_per_batch + r;
+            const int ii = idx[row];
+            const float4 *src = p + (size_t)ii * c4;
+            float4 *dst = out + row * c4;
+            for (int l = lx; l < c4; l += LW) dst[l] = src[l];
+        }
+    }
+}
+
 template <int LW>
 __global__ __launch_bounds__(kRowThreads) void three_interpolate_kernel(
-    int b, int m, int c, int n, const float *__restrict__ points, const int *__restrict__ idx,
+    int b, int m, int c, int n, int vec, const float *__restrict__ points, const int *__restrict__ idx,
     const float *__restrict__ weight, float *__restrict__ out)
 {
     constexpr int RPB = kRowThreads / LW;
     const int lx = threadIdx.x % LW, ly = threadIdx.x / LW;
-    for (int bi = blockIdx.y; bi < b; bi += gridDim.y) {
+    const BlockXY blk = frustum_major_block();
+    for (int bi = blk.y; bi < b; bi += gridDim.y) {
         const float *p = points + (size_t)bi * m * c;
-        for (int r = blockIdx.x * RPB + ly; r < n; r += gridDim.x * RPB) {
+        for (int r = blk.x * RPB + ly; r < n; r += gridDim.x * RPB) {
             const size_t row = (size_t)bi * n + r;
             const int i1 = idx[row * 3 + 0], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
             const float w1 = weight[row * 3 + 0], w2 = weight[row * 3 + 1], w3 = weight[row * 3 + 2];
             const float *p1 = p + (size_t)i1 * c, *p2 = p + (size_t)i2 * c, *p3 = p + (size_t)i3 * c;
             float *dst = out + row * c;
-            for (int l = lx; l < c; l += LW) {
-                float s = p1[l] * w1 + p2[l] * w2;
-                dst[l] = s + p3[l] * w3;
+            if (vec) {   // c % 4 == 0 and 16-byte aligned arrays: the same sums, four channels per lane
+                const float4 *q1 = reinterpret_cast<const float4 *>(p1), *q2 = reinterpret_cast<const float4 *>(p2),
+                             *q3 = reinterpret_cast<const float4 *>(p3);
+                float4 *d4 = reinterpret_cast<float4 *>(dst);
+                for (int l = lx; l < c / 4; l += LW) {
+                    const float4 a = q1[l], bq = q2[l], cq = q3[l];
+                    float4 t;
+                    t.x = a.x * w1 + bq.x * w2; t.y = a.y * w1 + bq.y * w2;
+                    t.z = a.z * w1 + bq.z * w2; t.w = a.w * w1 + bq.w * w2;
+                    t.x = t.x + cq.x * w3; t.y = t.y + cq.y * w3; t.z = t.z + cq.z * w3; t.w = t.w + cq.w * w3;
+                    d4[l] = t;
+                }
+            } else {
+                for (int l = lx; l < c; l += LW) {
+                    float s = p1[l] * w1 + p2[l] * w2;
+                    dst[l] = s + p3[l] * w3;
+                }
             }
         }
     }
@@ -442,8 +502,9 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(
     float *__restrict__ dist, int *__restrict__ idx)
 {
     __shared__ float4 tile[kNnTile];
-    const int bi = blockIdx.y;
-    const int j = blockIdx.x * kNnThreads + threadIdx.x;
+    const BlockXY blk = frustum_major_block();
+    const int bi = blk.y;
+    const int j = blk.x * kNnThreads + threadIdx.x;
     const bool active = j < n;
     const size_t row = (size_t)bi * n + (active ? j : 0);
     const float x1 = xyz1[row * 3 + 0], y1 = xyz1[row * 3 + 1], z1 = xyz1[row * 3 + 2];
@@ -467,15 +528,16 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(
 // whole workgroup write the 256 output rows with lanes along the channel axis.
 template <int LW>
 __global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_kernel(
-    int n, int m, int c, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    int n, int m, int c, int vec, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     const float *__restrict__ points2, float *__restrict__ out, float *__restrict__ dist,
     int *__restrict__ idx)
 {
     __shared__ float4 tile[kNnTile];
     __shared__ int s_i[kNnThreads * 3];
     __shared__ float s_w[kNnThreads * 3];
-    const int bi = blockIdx.y;
-    const int j0 = blockIdx.x * kNnThreads;
+    const BlockXY blk = frustum_major_block();
+    const int bi = blk.y;
+    const int j0 = blk.x * kNnThreads;
     const int j = j0 + threadIdx.x;
     const bool active = j < n;
     const size_t row = (size_t)bi * n + (active ? j : 0);
@@ -518,9 +580,23 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_kernel(
         const float w1 = s_w[r * 3 + 0], w2 = s_w[r * 3 + 1], w3 = s_w[r * 3 + 2];
         const float *p1 = p + (size_t)i1 * c, *p2 = p + (size_t)i2 * c, *p3 = p + (size_t)i3 * c;
         float *dst = out + ((size_t)bi * n + j0 + r) * c;
-        for (int l = lx; l < c; l += LW) {
-            float t = p1[l] * w1 + p2[l] * w2;
-            dst[l] = t + p3[l] * w3;
+        if (vec) {       // c % 4 == 0 and 16-byte aligned arrays: the same sums, four channels per lane
+            const float4 *q1 = reinterpret_cast<const float4 *>(p1), *q2 = reinterpret_cast<const float4 *>(p2),
+                         *q3 = reinterpret_cast<const float4 *>(p3);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            for (int l = lx; l < c / 4; l += LW) {
+                const float4 a = q1[l], bq = q2[l], cq = q3[l];
+                float4 t;
+                t.x = a.x * w1 + bq.x * w2; t.y = a.y * w1 + bq.y * w2;
+                t.z = a.z * w1 + bq.z * w2; t.w = a.w * w1 + bq.w * w2;
+                t.x = t.x + cq.x * w3; t.y = t.y + cq.y * w3; t.z = t.z + cq.z * w3; t.w = t.w + cq.w * w3;
+                d4[l] = t;
+            }
+        } else {
+            for (int l = lx; l < c; l += LW) {
+                float t = p1[l] * w1 + p2[l] * w2;
+                dst[l] = t + p3[l] * w3;
+            }
         }
     }
 }
@@ -804,10 +880,18 @@ int fpn_group_point(int b, int n, int c, int m, int nsample, const float *points
     if (b == 0 || rows == 0 || c == 0) return FPN_OK;
     FPN_REQUIRE(points && idx && out, "group_point: null pointer");
     FPN_REQUIRE(rows <= INT32_MAX, "group_point: m*nsample too large");
+    hipStream_t st = as_stream(stream);
+    if (c % 4 == 0 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const int lw = pow2_at_least(c / 4);
+        const int rpb = kRowThreads / lw;
+        dim3 grid((unsigned)std::min<long>((rows + rpb - 1) / rpb, 1 << 20), (unsigned)std::min(b, 65535));
+        FPN_DISPATCH_LW(lw, group_point_vec_kernel, grid, dim3(kRowThreads), 0, st, b, n, c / 4, (int)rows,
+                        reinterpret_cast<const float4 *>(points), idx, reinterpret_cast<float4 *>(out))
+        return check_launch("fpn_group_point");
+    }
     const int lw = pow2_at_least(c);
     const int rpb = kRowThreads / lw;
     dim3 grid((unsigned)std::min<long>((rows + rpb - 1) / rpb, 1 << 20), (unsigned)std::min(b, 65535));
-    hipStream_t st = as_stream(stream);
     FPN_DISPATCH_LW(lw, group_point_kernel, grid, dim3(kRowThreads), 0, st, b, n, c, (int)rows, points,
                     idx, out)
     return check_launch("fpn_group_point");
@@ -832,11 +916,12 @@ int fpn_three_interpolate(int b, int m, int c, int n, const float *points, const
     FPN_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0, "three_interpolate: negative size");
     if (b == 0 || n == 0 || c == 0) return FPN_OK;
     FPN_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
-    const int lw = pow2_at_least(c);
+    const int vec = c % 4 == 0 && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int lw = pow2_at_least(vec ? c / 4 : c);
     const int rpb = kRowThreads / lw;
     dim3 grid((unsigned)std::min<long>(((long)n + rpb - 1) / rpb, 1 << 20), (unsigned)std::min(b, 65535));
     hipStream_t st = as_stream(stream);
-    FPN_DISPATCH_LW(lw, three_interpolate_kernel, grid, dim3(kRowThreads), 0, st, b, m, c, n, points, idx,
+    FPN_DISPATCH_LW(lw, three_interpolate_kernel, grid, dim3(kRowThreads), 0, st, b, m, c, n, vec, points, idx,
                     weight, out)
     return check_launch("fpn_three_interpolate");
 }
@@ -848,10 +933,12 @@ int fpn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1, cons
     if (b == 0 || n == 0) return FPN_OK;
     FPN_REQUIRE(xyz1 && xyz2 && points2 && out, "three_nn_interpolate: null pointer");
     FPN_REQUIRE(b <= 65535, "three_nn_interpolate: batch %d exceeds 65535", b);
-    const int lw = pow2_at_least(c > 0 ? c : 1);
+    const int vec = c > 0 && c % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(points2) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int lw = pow2_at_least(c > 0 ? (vec ? c / 4 : c) : 1);
     dim3 grid((n + kNnThreads - 1) / kNnThreads, b);
     hipStream_t st = as_stream(stream);
-    FPN_DISPATCH_LW(lw, three_nn_interpolate_kernel, grid, dim3(kNnThreads), 0, st, n, m, c, xyz1, xyz2,
+    FPN_DISPATCH_LW(lw, three_nn_interpolate_kernel, grid, dim3(kNnThreads), 0, st, n, m, c, vec, xyz1, xyz2,
                     points2, out, dist, idx)
     return check_launch("fpn_three_nn_interpolate");
 }

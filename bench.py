@@ -150,7 +150,13 @@ def pointset_ops(dev, frustums=256, reps=20):
                                                 12 * (N + M) + 4 * M * C + 4 * N * C),
     }
     out = {}
+    # FPN_POINTSET_SYNC=1 (counter runs): one launch on the device at a time, so that a
+    # dispatch's hardware counters hold its own traffic only
+    isolate = os.environ.get("FPN_POINTSET_SYNC") == "1"
     for name, (fn, bytes_per_frustum) in cases.items():
+        if isolate:
+            inner = fn
+            fn = lambda inner=inner: (inner(), torch.cuda.synchronize())      # noqa: E731
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
