@@ -780,10 +780,11 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)blockIdx.x * kRegWaves + (threadIdx.x >> 6)) * 32;
+    const unsigned block = logical_block(1);      // a frustum's balls gather from the same arrays: one XCD
+    const long row0 = ((long)block * kRegWaves + (threadIdx.x >> 6)) * 32;
     constexpr int C = 32 * NT3;
     __shared__ int lmax[4 * C];
-    const WgPool pool = wg_pool(p.rows, p.ns, blockIdx.x);
+    const WgPool pool = wg_pool(p.rows, p.ns, block);
     if (!pool.on && row0 >= p.rows) return;
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long ball = row0 / p.ns;                    // = b * m + j
