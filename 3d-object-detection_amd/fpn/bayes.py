@@ -72,6 +72,7 @@ class BayesPlan:
         init_variables(store, pc_channels)
         self.table = _plan.layer_table(pc_channels)
         self._ones = {}
+        self._w6_glob = None
 
     # ---- noise -------------------------------------------------------------
     def sample_noise(self, nsamples, batch, generator=None, points=None):
@@ -152,6 +153,7 @@ class BayesPlan:
     # frustum copies (sample x frustum pairs) per pass of the chain path: each carries
     # 2.4 MB of effective weights
     CHAIN_COPIES = 1024
+    SAMPLE_BLOCK = 64
 
     def _forward_chain(self, point_cloud, one_hot_vec, nsamples, noise, drop=None):
         """All samples of a block of frustums stacked along the frustum axis: a pass of
@@ -161,25 +163,33 @@ class BayesPlan:
         budget = self.chunk_frustums or self.CHAIN_COPIES
         sig = {k: self._sigma(k) for k in noise}
         result = {}
-        for lo in range(0, b, budget):
-            hi = min(b, lo + budget)
-            bb = hi - lo
-            group = max(1, budget // bb)                 # samples per pass
-            for s0 in range(0, nsamples, group):
-                s1 = min(nsamples, s0 + group)
-                sp = s1 - s0
-                nz = {k: ((sig[k] * v[0][s0:s1]).contiguous(),
-                          v[1][s0:s1, lo:hi].reshape(sp * bb, -1).contiguous(),
-                          v[2][s0:s1, lo:hi].reshape(sp * bb, -1).contiguous())
-                      for k, v in noise.items()}
-                pc = point_cloud[lo:hi].repeat(sp, 1, 1) if sp > 1 else point_cloud[lo:hi].contiguous()
-                oh = one_hot_vec[lo:hi].repeat(sp, 1) if sp > 1 else one_hot_vec[lo:hi].contiguous()
-                dm = None if drop is None else drop[s0:s1, lo:hi].reshape(sp * bb * n, 4).contiguous()
-                ep = self._forward_chunk_chain(pc, oh, nz, sp, dm)
-                for k, v in ep.items():
-                    if k not in result:
-                        result[k] = torch.empty((nsamples, b) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-                    result[k][s0:s1, lo:hi] = v.reshape((sp, bb) + tuple(v.shape[1:]))
+        # the perturbations sigma * eps of a block of samples are formed once (one launch per
+        # layer and block, not per pass); a block holds at most SAMPLE_BLOCK samples x 9 MB
+        for q0 in range(0, nsamples, self.SAMPLE_BLOCK):
+            q1 = min(nsamples, q0 + self.SAMPLE_BLOCK)
+            dws = {k: sig[k] * v[0][q0:q1] for k, v in noise.items()}
+            for lo in range(0, b, budget):
+                hi = min(b, lo + budget)
+                bb = hi - lo
+                whole = lo == 0 and hi == b              # (then the sign slices below are views)
+                group = max(1, budget // bb)             # samples per pass
+                pcs, ohs = point_cloud[lo:hi].contiguous(), one_hot_vec[lo:hi].contiguous()
+                rep = None
+                for s0 in range(q0, q1, group):
+                    s1 = min(q1, s0 + group)
+                    sp = s1 - s0
+                    nz = {k: (dws[k][s0 - q0:s1 - q0],
+                              v[1][s0:s1].reshape(sp * bb, -1) if whole else v[1][s0:s1, lo:hi].reshape(sp * bb, -1),
+                              v[2][s0:s1].reshape(sp * bb, -1) if whole else v[2][s0:s1, lo:hi].reshape(sp * bb, -1))
+                          for k, v in noise.items()}
+                    if rep is None or rep[0] != sp:      # the repeated inputs are the same for every pass of a block
+                        rep = (sp, pcs.repeat(sp, 1, 1) if sp > 1 else pcs, ohs.repeat(sp, 1) if sp > 1 else ohs)
+                    dm = None if drop is None else drop[s0:s1, lo:hi].reshape(sp * bb * n, 4).contiguous()
+                    ep = self._forward_chunk_chain(rep[1], rep[2], nz, sp, dm)
+                    for k, v in ep.items():
+                        if k not in result:
+                            result[k] = torch.empty((nsamples, b) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                        result[k][s0:s1, lo:hi] = v.reshape((sp, bb) + tuple(v.shape[1:]))
         return result
 
     def _eff(self, scope, nz, layout, rows=None):
@@ -246,7 +256,9 @@ class BayesPlan:
             ops.v1_seg_head(pc.reshape(b * n, c), n, ops.pointer_table(head), point_feat, gcat, per_frustum=True)
         dw6, si6, so6 = nz["conv6"]
         w6 = st["conv6/weights"]
-        gshift = ops.shared_mlp_flipout(gcat, w6[64:].contiguous(), dw6[:, 64:].contiguous(), b // samples,
+        if self._w6_glob is None or self._w6_glob[0] != st.version:
+            self._w6_glob = (st.version, w6[64:].contiguous())       # rows of the frustum-constant inputs
+        gshift = ops.shared_mlp_flipout(gcat, self._w6_glob[1], dw6[:, 64:].contiguous(), b // samples,
                                         si6[:, 64:].contiguous(), so6, 1, scale=None, shift=st["conv6/biases"],
                                         relu=False)
         logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
