@@ -332,8 +332,9 @@ def main():
                     help="--config v2: frustums per GPU held in host memory and streamed through the model in "
                          "chunks of --batch (BASELINE config 5's access pattern); a step = the whole set")
     ap.add_argument("--samples", type=int, default=32, help="Monte-Carlo samples per frustum (--config bayes)")
-    ap.add_argument("--mc-dropout", action="store_true",
-                    help="--config bayes: keep the Dropout(0.5) before the segmentation head active (Monte-Carlo dropout)")
+    ap.add_argument("--mc-dropout", action=argparse.BooleanOptionalAction, default=True,
+                    help="--config bayes: keep the Dropout(0.5) before the segmentation head active (Monte-Carlo "
+                         "dropout, as BASELINE's Bayesian configuration samples; --no-mc-dropout: Flipout noise only)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="operand type of the layer-chain kernels' matrix products (accumulation is always fp32); "
                          "f32 is the headline configuration")
