@@ -7,8 +7,6 @@ leading sample axis plus end_points['mc_statistics'] (B,30), the ensemble statis
 fpn.uncertainty.  `Frustum_Pointnet_Model(...)` keeps the reference constructor
 (:140-223): (training_model, det_model), each det_model call drawing fresh noise.
 """
-import torch
-
 from .. import bayes as _bayes
 from .. import tf_util, uncertainty, variables
 from ._keras_like import DetectionModel, TrainingModelStub

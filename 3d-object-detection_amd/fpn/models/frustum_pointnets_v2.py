@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from .. import tf_util, variables
+from .. import tf_util
 from ..model_util import (NUM_HEADING_BIN, NUM_SIZE_CLUSTER, get_center_regression_net,
                           parse_output_to_tensors, point_cloud_masking)
 from ..pointnet_util import (pointnet_fp_module, pointnet_fp_module_with_head, pointnet_sa_module,

@@ -17,11 +17,9 @@ Keras / Flipout re-statements) as a fixed sequence of libfpn_hip.so calls:
 In Flipout mode (models/FPointNet_Bayes.py) S Monte-Carlo samples of every frustum
 are stacked along the row axis and go through the same kernels in one pass.
 """
-import math
-
 import torch
 
-from . import model_util, ops, variables
+from . import model_util, ops
 
 SEG_HEAD = [("conv1", 64), ("conv2", 64), ("conv3", 64), ("conv4", 128), ("conv5", 1024)]
 SEG_TAIL = [("conv6", 512), ("conv7", 256), ("conv8", 128), ("conv9", 128)]

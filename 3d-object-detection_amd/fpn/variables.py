@@ -13,7 +13,6 @@ creates them).  Convolution kernels are held as (Cin,Cout); a TF checkpoint's
 import contextlib
 import math
 
-import numpy as np
 import torch
 
 BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default epsilon, models/tf_util.py:527-531

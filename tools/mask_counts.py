@@ -1,4 +1,4 @@
-import sys, os
+import sys
 sys.path.insert(0, "3d-object-detection_amd")
 import torch
 from fpn import plan, synthetic, variables
