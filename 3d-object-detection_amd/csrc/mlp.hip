@@ -408,7 +408,7 @@ int check_common(const char *who, long rows, int cin, int cout, const float *x, 
 {
     FPN_REQUIRE(rows >= 0 && cin >= 1 && cout >= 1, "%s: bad size rows=%ld cin=%d cout=%d", who, rows, cin, cout);
     FPN_REQUIRE(ldx >= cin && ldy >= cout, "%s: row stride smaller than the channel count", who);
-    FPN_REQUIRE(x && w && y, "%s: null pointer", who);
+    FPN_REQUIRE(rows == 0 || (x && w && y), "%s: null pointer", who);     // (an empty batch has no buffers)
     if (pool_rows) {
         FPN_REQUIRE(pool_rows > 0 && pool_rows % 32 == 0, "%s: pool_rows=%d must be a positive multiple of 32", who, pool_rows);
         FPN_REQUIRE(rows % pool_rows == 0, "%s: rows=%ld is not a multiple of pool_rows=%d", who, rows, pool_rows);
@@ -476,7 +476,7 @@ int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int
 {
     int rc = check_common("shared_mlp_flipout", rows, cin, cout, x, ldx, w_mean, pool_rows, y, ldy, workspace, workspace_bytes);
     if (rc != FPN_OK) return rc;
-    FPN_REQUIRE(w_delta && sign_in && sign_out, "shared_mlp_flipout: null pointer");
+    FPN_REQUIRE(rows == 0 || (w_delta && sign_in && sign_out), "shared_mlp_flipout: null pointer");
     FPN_REQUIRE(rows_per_group >= 1 && rows_per_sample >= 1, "shared_mlp_flipout: rows_per_group / rows_per_sample must be >= 1");
     FPN_REQUIRE(rows % rows_per_sample == 0 && rows_per_sample % rows_per_group == 0,
                 "shared_mlp_flipout: rows (%ld) must split into samples (%ld) and samples into groups (%d)",

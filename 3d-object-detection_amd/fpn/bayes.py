@@ -163,6 +163,15 @@ class BayesPlan:
         budget = self.chunk_frustums or self.CHAIN_COPIES
         sig = {k: self._sigma(k) for k in noise}
         result = {}
+        if b == 0:       # an empty batch: the end points with zero frustums, nothing to launch
+            dev = point_cloud.device
+            z = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=dev)     # noqa: E731
+            m = model_util.NUM_OBJECT_POINT
+            ep = {"mask_logits": z(0, n, 2), "mask": z(0, n), "object_point_indices": z(0, m, dtype=torch.int32),
+                  "mask_xyz_mean": z(0, 3), "center_delta": z(0, 3), "stage1_center": z(0, 3), "box_output": z(0, 59)}
+            model_util.parse_output_to_tensors(ep["box_output"], ep)
+            ep["center"] = ep["center_boxnet"] + ep["stage1_center"]
+            return {k: v.new_empty((nsamples,) + tuple(v.shape)) for k, v in ep.items()}
         # the perturbations sigma * eps of a block of samples are formed once (one launch per
         # layer and block, not per pass); a block holds at most SAMPLE_BLOCK samples x 9 MB
         for q0 in range(0, nsamples, self.SAMPLE_BLOCK):

@@ -149,7 +149,7 @@ def get_center_regression_net(object_point_cloud, one_hot_vec, is_training, bn_d
     net = tf_util.conv2d(net, 256, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                          is_training=is_training, scope='conv-reg3-stage1', bn_decay=bn_decay)
     net = tf_util.max_pool2d(net, [num_point, 1], padding='VALID', scope='maxpool-stage1')
-    net = net.reshape(net.shape[0], -1)
+    net = net.reshape(net.shape[0], math.prod(net.shape[1:]))
     net = torch.cat([net, one_hot_vec], dim=1)
     net = tf_util.fully_connected(net, 256, scope='fc1-stage1', bn=True, is_training=is_training,
                                   bn_decay=bn_decay)

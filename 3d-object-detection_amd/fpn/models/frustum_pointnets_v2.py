@@ -63,7 +63,7 @@ def get_3d_box_estimation_v2_net(object_point_cloud, one_hot_vec, is_training, b
     _, l3_points, _ = pointnet_sa_module(l2_xyz, l2_points, npoint=None, radius=None, nsample=None,
                                          mlp=c["sa3"]["mlp"], mlp2=None, group_all=True,
                                          is_training=is_training, bn_decay=bn_decay, scope='ssg-layer3')
-    net = l3_points.reshape(l3_points.shape[0], -1)
+    net = l3_points.reshape(l3_points.shape[0], l3_points.shape[1] * l3_points.shape[2])
     net = torch.cat([net, one_hot_vec], dim=1)
     net = tf_util.fully_connected(net, 512, bn=True, is_training=is_training, scope='fc1', bn_decay=bn_decay)
     net = tf_util.fully_connected(net, 256, bn=True, is_training=is_training, scope='fc2', bn_decay=bn_decay)

@@ -148,6 +148,13 @@ class V1Plan:
         w, scale, shift, relu = self.p[scope]
         return ops.shared_mlp(x, w, scale, shift, relu=relu, **kw)
 
+    def _pooled_layer(self, x, scope, pool_rows, out):
+        """Layer + max over groups of pool_rows rows: fused into the layer's epilogue for the
+        group sizes the kernel pools (32, 64, multiples of 128), a separate pass otherwise."""
+        if pool_rows in (32, 64) or pool_rows % 128 == 0:
+            return self._layer(x, scope, pool_rows=pool_rows, out=out)
+        return ops.max_pool_rows(self._layer(x, scope), pool_rows, out=out)
+
     def default_chunk(self, n):
         # largest per-point activation set alive at once is conv6's 512 floats out +
         # conv7's 256: ~3.6 KB per point with the smaller buffers; a chunk of 1 GiB
@@ -170,7 +177,7 @@ class V1Plan:
             raise ValueError("the fused max-pool needs the number of points per frustum to be a multiple of 32")
         chunk = self.chunk_frustums or self.default_chunk(n)
         outs = []
-        for s in range(0, b, chunk):
+        for s in range(0, max(b, 1), chunk):      # (an empty batch still makes one, empty, pass)
             outs.append(self._forward_chunk(point_cloud[s:s + chunk], one_hot_vec[s:s + chunk]))
         ep = {}
         for k in outs[0]:
@@ -210,7 +217,7 @@ class V1Plan:
             a = self._layer(a, "conv2")
             point_feat = self._layer(a, "conv3")
             a = self._layer(point_feat, "conv4")
-            self._layer(a, "conv5", pool_rows=n, out=gcat[:, :1024])      # conv5 + maxpool :57-62
+            self._pooled_layer(a, "conv5", n, gcat[:, :1024])             # conv5 + maxpool :57-62
             del a
             gbias = ops.shared_mlp(gcat, self.w6_glob, None, None, relu=False)
             _, scale6, shift6, _ = self.p["conv6"]
@@ -239,7 +246,7 @@ class V1Plan:
         else:
             t = self._layer(obj2d, "conv-reg1-stage1")
             t = self._layer(t, "conv-reg2-stage1")
-            self._layer(t, "conv-reg3-stage1", pool_rows=m, out=tcat[:, :256])
+            self._pooled_layer(t, "conv-reg3-stage1", m, tcat[:, :256])
         t = self._layer(tcat, "fc1-stage1")
         t = self._layer(t, "fc2-stage1")
         center_delta = self._layer(t, "fc3-stage1")
@@ -260,7 +267,7 @@ class V1Plan:
             t = self._layer(obj_new, "conv-reg1")
             t = self._layer(t, "conv-reg2")
             t = self._layer(t, "conv-reg3")
-            self._layer(t, "conv-reg4", pool_rows=m, out=bcat[:, :512])
+            self._pooled_layer(t, "conv-reg4", m, bcat[:, :512])
         t = self._layer(bcat, "fc1")
         t = self._layer(t, "fc2")
         output = self._layer(t, "fc3")

@@ -217,7 +217,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             pooled = torch.empty((xyz.shape[0] * npoint, mlp[-1]), dtype=torch.float32, device=xyz.device)
             if _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx.contiguous(), mlp,
                          'conv%d', bn, pooled, xyz_first=True):
-                return new_xyz, pooled.reshape(xyz.shape[0], npoint, -1), idx
+                return new_xyz, pooled.reshape(xyz.shape[0], npoint, pooled.shape[-1]), idx
         if group_all:
             nsample = xyz.shape[1]
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
@@ -229,7 +229,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if pooling == 'max':
             pooled = _mlp_stack(x2d, mlp, 'conv%d', bn, pool_rows=ns)                    # :116-126
         else:
-            feat = _mlp_stack(x2d, mlp, 'conv%d', bn).reshape(b, m, ns, -1)
+            feat = _mlp_stack(x2d, mlp, 'conv%d', bn)
+            feat = feat.reshape(b, m, ns, feat.shape[-1])
             if pooling == 'avg':
                 pooled = feat.mean(dim=2)
             elif pooling == 'weighted_avg':                                              # :129-135
@@ -241,10 +242,10 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 pooled = torch.cat([feat.mean(dim=2), feat.amax(dim=2)], dim=-1)
             else:
                 raise ValueError("unknown pooling %r" % pooling)
-            pooled = pooled.reshape(b * m, -1).contiguous()
+            pooled = pooled.reshape(b * m, pooled.shape[-1]).contiguous()
         if mlp2 is not None:
             pooled = _mlp_stack(pooled, mlp2, 'conv_post_%d', bn)                        # :142-150
-        return new_xyz, pooled.reshape(b, m, -1), idx
+        return new_xyz, pooled.reshape(b, m, pooled.shape[-1]), idx
 
 
 def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training, bn_decay,
@@ -289,7 +290,7 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated  # :218
         b, n, c = new_points1.shape
         y = _mlp_stack(new_points1.reshape(b * n, c).contiguous(), mlp, 'conv_%d', bn)                  # :222-226
-        return y.reshape(b, n, -1)
+        return y.reshape(b, n, y.shape[-1])
 
 
 def _fp_head_plan(store, names, cb, bn):

@@ -165,6 +165,19 @@ def test_v1_chunking_and_sizes(device):
     compare_end_points(a, want, pc, one_hot, st.numpy())
 
 
+@pytest.mark.parametrize("b,n,chain", [(1, 1024, True), (1, 32, True), (2, 4096, True), (1, 96, False), (1, 160, True)])
+def test_v1_single_frustums_and_extreme_point_counts(device, b, n, chain):
+    """One frustum per call (grids of a handful of workgroups), the smallest point count a
+    wave can carry (32), a large one (4096), counts that are no multiple of 128."""
+    from fpn import plan, synthetic
+    st = make_store(device, seed=4)
+    pc, one_hot = synthetic.make_frustums(b, n, 4, seed=n)
+    ep = plan.V1Plan(st, 4, True, chain=chain).forward(dev(pc, device), dev(one_hot, device))
+    compare_end_points(ep, V.get_model(pc, one_hot, st.numpy()), pc, one_hot, st.numpy())
+    with pytest.raises(ValueError):
+        plan.V1Plan(st, 4, True).forward(dev(pc[:, :n - 1], device), dev(one_hot, device))
+
+
 def test_v1_oracle_fp64_error_budget(device):
     """Both fp32 evaluations (GPU, numpy) sit equally close to the float64 value."""
     from fpn import plan, synthetic

@@ -113,11 +113,12 @@ def test_sa_msg_and_fp_modules(device):
     close(up.cpu().numpy(), wu)
 
 
-def test_v2_get_model_config2(device):
-    """BASELINE config 2: v2 topology on 2048-point frustums."""
+@pytest.mark.parametrize("b,n", [(3, 2048), (1, 2048), (1, 512)])
+def test_v2_get_model_config2(device, b, n):
+    """BASELINE config 2: v2 topology on 2048-point frustums; a single frustum; fewer points."""
     from fpn import synthetic, variables
     from fpn.models import frustum_pointnets_v2 as M2
-    pc, one_hot = synthetic.make_frustums(3, 2048, 4, seed=2)
+    pc, one_hot = synthetic.make_frustums(b, n, 4, seed=2)
     pc[..., :3] *= 0.05      # bring the metric frustum into the radius range of the SA modules
     st = fresh_store(device, seed=7)
     with variables.use_store(st):
@@ -138,7 +139,7 @@ def test_v2_get_model_config2(device):
     gdelta = ep["center_delta"].cpu().numpy()
     out = P.v2_box_estimation(obj - gdelta[:, None, :], one_hot, params, M2.CONFIG)
     close(ep["box_output"].cpu().numpy(), out)
-    assert ep["center"].shape == (3, 3) and ep["size_residuals"].shape == (3, 8, 3)
+    assert ep["center"].shape == (b, 3) and ep["size_residuals"].shape == (b, 8, 3)
 
 
 def test_sa_chain_kernels(device):

@@ -278,3 +278,61 @@ def test_query_group_interpolate_full_size_properties(device):
     od, on = O.three_nn(x[sub], x[sub][:, :M])
     np.testing.assert_array_equal(nn[sub].cpu().numpy(), on)
     np.testing.assert_array_equal(dist[sub].cpu().numpy(), od)
+
+
+def test_zero_sized_inputs(device):
+    """Empty batches and empty query / sample sets: every operator returns an empty result
+    of the right shape without launching anything."""
+    from fpn import ops
+    from fpn.tf_ops.tf_grouping import group_point, query_ball_point
+    from fpn.tf_ops.tf_interpolate import three_interpolate, three_nn, three_nn_interpolate
+    from fpn.tf_ops.tf_sampling import farthest_point_sample, gather_point
+    f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
+    i = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=device)
+    assert farthest_point_sample(4, f(0, 16, 3)).shape == (0, 4)
+    assert gather_point(f(0, 16, 3), i(0, 4)).shape == (0, 4, 3)
+    assert gather_point(f(2, 16, 3), i(2, 0)).shape == (2, 0, 3)
+    idx, cnt = query_ball_point(0.5, 8, f(2, 16, 3), f(2, 0, 3))
+    assert idx.shape == (2, 0, 8) and cnt.shape == (2, 0)
+    idx, cnt = query_ball_point(0.5, 8, f(0, 16, 3), f(0, 5, 3))
+    assert idx.shape == (0, 5, 8) and cnt.shape == (0, 5)
+    assert group_point(f(2, 16, 7), i(2, 0, 8)).shape == (2, 0, 8, 7)
+    d, ix = three_nn(f(2, 0, 3), f(2, 5, 3))
+    assert d.shape == (2, 0, 3) and ix.shape == (2, 0, 3)
+    assert three_interpolate(f(2, 5, 7), i(2, 0, 3), f(2, 0, 3)).shape == (2, 0, 7)
+    assert three_nn_interpolate(f(0, 9, 3), f(0, 5, 3), f(0, 5, 7)).shape == (0, 9, 7)
+    assert ops.shared_mlp(f(0, 16), f(16, 32), None, None, relu=True).shape == (0, 32)
+    torch.cuda.synchronize()
+
+
+def test_zero_frustum_batch_through_the_models(device):
+    """A batch of zero frustums goes through the v1 plan (every kernel entry point sees an
+    empty problem) and comes back as empty end points."""
+    from fpn import plan, variables
+    st = variables.VariableStore(device, seed=1)
+    plan.init_variables(st, 4, True)
+    net = plan.V1Plan(st, 4, True)
+    ep = net.forward(torch.zeros((0, 1024, 4), device=device), torch.zeros((0, 3), device=device))
+    assert ep["mask_logits"].shape == (0, 1024, 2) and ep["box_output"].shape == (0, 59) and ep["center"].shape == (0, 3)
+
+
+@pytest.mark.parametrize("kind", ["v1_bf16", "v2", "bayes"])
+def test_zero_frustum_batch_other_models(device, kind):
+    from fpn import bayes, plan, variables
+    st = variables.VariableStore(device, seed=1)
+    pc, oh = torch.zeros((0, 256, 4), device=device), torch.zeros((0, 3), device=device)
+    if kind == "v1_bf16":
+        plan.init_variables(st, 4, True)
+        ep = plan.V1Plan(st, 4, True, precision="bf16").forward(pc, oh)
+        assert ep["mask_logits"].shape == (0, 256, 2) and ep["box_output"].shape == (0, 59)
+    elif kind == "v2":
+        from fpn.models import frustum_pointnets_v2 as M2
+        with variables.use_store(st):
+            M2.get_model(torch.zeros((2, 256, 4), device=device) + torch.rand((2, 256, 4), device=device),
+                         torch.eye(3, device=device)[:2], False)          # creates the variables
+            ep = M2.get_model(pc, oh, False)
+        assert ep["mask_logits"].shape == (0, 256, 2) and ep["box_output"].shape == (0, 59)
+    else:
+        bp = bayes.BayesPlan(st, 3)
+        ep = bp.forward(pc[:, :, :3].contiguous(), oh, 2)
+        assert ep["mask_logits"].shape == (2, 0, 256, 2) and ep["box_output"].shape == (2, 0, 59)
