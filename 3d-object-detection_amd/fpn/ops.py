@@ -119,7 +119,9 @@ def tile_weights_reg(w, jmajor):
 
 
 def _ld(t):
-    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    """Row stride of a 2-D tensor whose rows are dense; a single row has none that matters
+    (torch may report the stride of the wider tensor it was sliced from): its width."""
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
 
 def flipout_weights(w_mean, w_delta, sign_in, sign_out, layout, out=None):

@@ -243,3 +243,29 @@ def test_flipout_effective_weights_layouts(device):
             else:
                 ref = np.stack([ops.tile_weights_reg(dev(m, device), layout == 2).cpu().numpy() for m in want])
             np.testing.assert_array_equal(got.cpu().numpy(), ref.astype(np.float32), err_msg=str((cin, cout, layout)))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bayes_frustum_blocks_and_single_sample(device, precision):
+    """Frustum blocks smaller than the batch (sign matrices sliced per block, ragged last
+    block, several samples per pass) give exactly the results of one block; one frustum
+    with one sample runs."""
+    from fpn import bayes, synthetic, variables
+    st = variables.VariableStore(device, seed=6)
+    whole = bayes.BayesPlan(st, 3, precision=precision)
+    for k in list(st.keys()):
+        if k.endswith("/biases"):
+            st[k] = torch.randn(st[k].shape) * 0.1
+    B, N, S = 10, 128, 3
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=1)
+    g = torch.Generator(device=device)
+    g.manual_seed(3)
+    noise = whole.sample_noise(S, B, g)
+    a = whole.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+    for chunk in (4, 16):       # 4: blocks of 4, 4, 2 frustums, one sample per pass; 16: one block, one sample per pass
+        blocks = bayes.BayesPlan(st, 3, precision=precision, chunk_frustums=chunk)
+        b = blocks.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (chunk, k)
+    one = whole.forward(dev(pc[:1], device), dev(oh[:1], device), 1, generator=g)
+    assert one["box_output"].shape == (1, 1, 59) and torch.isfinite(one["box_output"]).all()

@@ -225,3 +225,26 @@ def test_bf16_bayes_within_stated_bound(device, B, N, dropout):
     assert max(worst.values()) <= BF16_RTOL, worst
     assert worst["mask_logits"] > 1e-5, "suspiciously exact: is the bf16 path running?"
     assert not torch.equal(ep["box_output"][0], ep["box_output"][1])
+
+
+def test_bf16_v2_single_frustum(device):
+    """The v2 topology with the bf16 set-abstraction kernels on one frustum (grids of a few
+    workgroups, no XCD regrouping) against the fp32 kernels under BF16_RTOL."""
+    from fpn import pointnet_util, synthetic, variables
+    from fpn.models import frustum_pointnets_v2 as M2
+    pc, one_hot = synthetic.make_frustums(1, 2048, 4, seed=5)
+    pc[..., :3] *= 0.05
+    st = variables.VariableStore(device, seed=3)
+    with variables.use_store(st):
+        M2.get_model(dev(pc, device), dev(one_hot, device), False)
+    st.randomize_batch_norm(4)
+    old = pointnet_util.SA_PRECISION
+    try:
+        with variables.use_store(st):
+            want = M2.get_model(dev(pc, device), dev(one_hot, device), False)["mask_logits"].cpu().numpy()
+            pointnet_util.SA_PRECISION = "bf16"
+            got = M2.get_model(dev(pc, device), dev(one_hot, device), False)["mask_logits"].cpu().numpy()
+    finally:
+        pointnet_util.SA_PRECISION = old
+    err = scaled_err(got, want)
+    assert 1e-6 < err <= BF16_RTOL, err
