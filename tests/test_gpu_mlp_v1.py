@@ -242,3 +242,37 @@ def test_v1_full_size_properties(device):
     assert torch.isfinite(full["box_output"]).all() and torch.isfinite(full["mask_logits"]).all()
     want = V.get_model(pc[sub], one_hot[sub], st.numpy())
     compare_end_points(alone, want, pc[sub], one_hot[sub], st.numpy())
+
+
+def test_two_streams_and_two_threads(device):
+    """The library keeps no state between calls: forwards enqueued on two HIP streams from
+    two Python threads at the same time give the results of the same forwards run alone."""
+    import threading
+    from fpn import plan, synthetic
+    st = make_store(device, seed=2)
+    net = plan.V1Plan(st, 4, True)
+    inputs = [tuple(dev(a, device) for a in synthetic.make_frustums(8, 512, 4, seed=s)) for s in (1, 2)]
+    alone = [net.forward(pc, oh) for pc, oh in inputs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=device) for _ in inputs]
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.device(device), torch.cuda.stream(streams[i]):
+                out = None
+                for _ in range(5):
+                    out = net.forward(*inputs[i])
+                streams[i].synchronize()
+                results[i] = out
+        except Exception as e:            # surfaced below: an exception in a thread would otherwise vanish
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for want, got in zip(alone, results):
+        for k in ("mask_logits", "box_output", "object_point_indices", "center"):
+            assert torch.equal(want[k], got[k]), k
