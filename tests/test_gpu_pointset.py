@@ -336,3 +336,52 @@ def test_zero_frustum_batch_other_models(device, kind):
         bp = bayes.BayesPlan(st, 3)
         ep = bp.forward(pc[:, :, :3].contiguous(), oh, 2)
         assert ep["mask_logits"].shape == (2, 0, 256, 2) and ep["box_output"].shape == (2, 0, 59)
+
+
+def test_pointset_random_shapes(device):
+    """Forty seeded random problems (batch, point counts, radius, samples per ball, channel
+    counts, duplicate fractions drawn at random, including single points and more samples
+    than points): every operator bit-exact against the oracle."""
+    from fpn.tf_ops.tf_grouping import group_point, knn_point, query_ball_point
+    from fpn.tf_ops.tf_interpolate import three_interpolate, three_nn, three_nn_interpolate
+    from fpn.tf_ops.tf_sampling import farthest_point_sample, gather_point
+    rng = np.random.RandomState(2024)
+    for trial in range(40):
+        b = int(rng.choice([1, 2, 3, 5, 8, 9]))
+        n = int(rng.choice([1, 2, 7, 33, 64, 100, 255, 256, 257, 700, 1500]))
+        m = int(rng.randint(1, min(n, 200) + 1))
+        ns = int(rng.choice([1, 3, 8, 32, 50, 64, 130]))
+        c = int(rng.choice([1, 2, 4, 5, 12, 32, 60, 64, 100]))
+        r = float(rng.choice([0.05, 0.2, 0.5, 2.0]))
+        x = clouds(b, n, seed=trial, dup=float(rng.choice([0.0, 0.3])))
+        tag = (trial, b, n, m, ns, c, r)
+        idx = farthest_point_sample(m, dev(x, device))
+        widx = O.farthest_point_sample(m, x)
+        np.testing.assert_array_equal(idx.cpu().numpy(), widx, err_msg=str(tag))
+        q = gather_point(dev(x, device), idx)
+        wq = O.gather_point(x, widx)
+        np.testing.assert_array_equal(q.cpu().numpy(), wq, err_msg=str(tag))
+        gi, cnt = query_ball_point(r, ns, dev(x, device), q)
+        wgi, wcnt = O.query_ball_point(r, ns, x, wq)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt, err_msg=str(tag))
+        np.testing.assert_array_equal(gi.cpu().numpy(), wgi, err_msg=str(tag))
+        feat = rng.standard_normal((b, n, c)).astype(np.float32)
+        np.testing.assert_array_equal(group_point(dev(feat, device), gi).cpu().numpy(), O.group_point(feat, wgi),
+                                      err_msg=str(tag))
+        d, i3 = three_nn(dev(x, device), q)
+        wd, wi3 = O.three_nn(x, wq)
+        np.testing.assert_array_equal(i3.cpu().numpy(), wi3, err_msg=str(tag))
+        np.testing.assert_array_equal(d.cpu().numpy(), wd, err_msg=str(tag))
+        f2 = rng.standard_normal((b, m, c)).astype(np.float32)
+        ww = O.fp_weights(wd)
+        want = O.three_interpolate(f2, wi3, ww)
+        np.testing.assert_array_equal(three_interpolate(dev(f2, device), i3, dev(ww, device)).cpu().numpy(), want,
+                                      err_msg=str(tag))
+        np.testing.assert_array_equal(three_nn_interpolate(dev(x, device), q, dev(f2, device)).cpu().numpy(), want,
+                                      err_msg=str(tag))
+        k = int(min(n, rng.choice([1, 3, 16])))
+        val, ki = knn_point(k, dev(x, device), q)
+        assert ki.shape == (b, m, k) and val.shape == (b, m, k), tag
+        # the k smallest squared distances, ascending (ties and rounding aside: compared as values)
+        d2 = ((wq[:, :, None, :].astype(np.float64) - x[:, None, :, :]) ** 2).sum(-1)
+        np.testing.assert_allclose(val.cpu().numpy(), np.sort(d2, -1)[..., :k], rtol=1e-5, atol=1e-6, err_msg=str(tag))
