@@ -160,7 +160,7 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
     b, n, _ = xyz.shape
     _, m, ns = idx.shape
     cf = 0 if points is None else points.shape[2]
-    if ns % 32 != 0 or len(widths) != 3:
+    if ns % 32 != 0 or len(widths) != 3 or widths[2] % 64 != 0:     # (the kernels write whole pairs of 32-wide tiles)
         return False
     store = variables.get_default_store()
     names = [variables.scoped(scope_fmt % i) for i in range(3)]

@@ -229,3 +229,75 @@ def test_fp_head_chain(device, cb):
     s = np.sqrt(np.mean(want ** 2))
     err = (np.abs(got - want) / np.maximum(np.abs(want), s)).max()
     assert 1e-6 < err <= 4e-2, err
+
+
+def test_sa_and_fp_modules_random_configurations(device):
+    """Twelve seeded random module configurations - sample counts that are no multiple of
+    32, one- to three-layer MLPs of odd widths, with and without features, group_all -
+    so that both the fused kernels and the per-layer fall-backs (and their un-fused
+    pooling) run; each against the numpy restatement."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(77)
+    for trial in range(12):
+        b = int(rng.choice([1, 2, 3]))
+        n = int(rng.choice([64, 200, 512]))
+        cf = int(rng.choice([0, 1, 5, 32]))
+        npoint = int(rng.choice([8, 16, 32]))
+        nsample = int(rng.choice([8, 20, 32, 64]))
+        radius = float(rng.choice([0.15, 0.3, 0.6]))
+        mlp = [int(w) for w in rng.choice([16, 24, 32, 64, 96, 128], size=int(rng.choice([1, 2, 3])))]
+        group_all = bool(trial % 4 == 3)
+        xyz, pts = cloud(b, n, max(cf, 1), 100 + trial)
+        pts = pts if cf else None
+        st = fresh_store(device, seed=trial)
+        scope = "sa%d" % trial
+        args = (None, None, None) if group_all else (npoint, radius, nsample)
+        for rnd in (0, 1):
+            with variables.use_store(st):
+                new_xyz, feat, idx = U.pointnet_sa_module(dev(xyz, device), None if pts is None else dev(pts, device),
+                                                          *args, mlp, None, group_all, False, None, scope=scope)
+            if rnd == 0:
+                st.randomize_batch_norm(trial)
+        wx, wf = P.sa_module(xyz, pts, args[0], args[1], args[2], mlp, group_all, st.numpy(), scope)
+        tag = (trial, b, n, cf, npoint, nsample, radius, mlp, group_all)
+        np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx, err_msg=str(tag))
+        close(feat.cpu().numpy(), wf)
+        # propagate back to the dense points through an FP module of random widths
+        fp_mlp = [int(w) for w in rng.choice([16, 40, 128], size=int(rng.choice([1, 2])))]
+        with variables.use_store(st):
+            up = U.pointnet_fp_module(dev(xyz, device), new_xyz, None if pts is None else dev(pts, device), feat,
+                                      fp_mlp, False, None, scope=scope + "fp")
+        wu = P.fp_module(xyz, wx, pts, wf, fp_mlp, st.numpy(), scope + "fp")
+        assert up.shape == (b, n, fp_mlp[-1]), tag
+        close(up.cpu().numpy(), wu)
+
+
+def test_sa_msg_random_configurations(device):
+    """Multi-scale grouping with random branches: fused and per-layer branches side by side
+    in one output buffer (column slices of different widths)."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(5)
+    for trial in range(8):
+        b, n = int(rng.choice([1, 2])), int(rng.choice([128, 300, 1024]))
+        cf = int(rng.choice([0, 1, 3, 64]))
+        npoint = int(rng.choice([16, 32]))
+        nb = int(rng.choice([1, 2, 3]))
+        radii = [float(r) for r in rng.choice([0.1, 0.2, 0.4, 0.8], size=nb)]
+        nsamples = [int(s) for s in rng.choice([16, 32, 40, 64, 128], size=nb)]
+        mlps = [[int(w) for w in rng.choice([32, 48, 64, 96, 128], size=3)] for _ in range(nb)]
+        xyz, pts = cloud(b, n, max(cf, 1), 200 + trial)
+        pts = pts if cf else None
+        st = fresh_store(device, seed=10 + trial)
+        scope = "msg%d" % trial
+        for rnd in (0, 1):
+            with variables.use_store(st):
+                new_xyz, feat = U.pointnet_sa_module_msg(dev(xyz, device), None if pts is None else dev(pts, device),
+                                                         npoint, radii, nsamples, mlps, False, None, scope=scope)
+            if rnd == 0:
+                st.randomize_batch_norm(trial)
+        wx, wf = P.sa_module_msg(xyz, pts, npoint, radii, nsamples, mlps, st.numpy(), scope)
+        np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx, err_msg=str((trial, radii, nsamples, mlps)))
+        assert feat.shape == (b, npoint, sum(m[-1] for m in mlps))
+        close(feat.cpu().numpy(), wf)
