@@ -276,3 +276,44 @@ def test_two_streams_and_two_threads(device):
     for want, got in zip(alone, results):
         for k in ("mask_logits", "box_output", "object_point_indices", "center"):
             assert torch.equal(want[k], got[k]), k
+
+
+def test_layer_random_shapes_and_options(device):
+    """Thirty seeded random layers: odd row / channel counts, optional scale, shift, ReLU,
+    per-group bias, fused pooling, input and output as column slices of wider buffers."""
+    from fpn import ops
+    rng = np.random.RandomState(99)
+    for trial in range(30):
+        pool = int(rng.choice([0, 0, 32, 64, 128, 256]))
+        groups = int(rng.randint(1, 12))
+        rows = groups * pool if pool else int(rng.choice([1, 5, 31, 32, 33, 100, 129, 1000, 2500]))
+        cin = int(rng.choice([1, 3, 4, 31, 64, 100, 259, 515, 1027]))
+        cout = int(rng.choice([1, 2, 3, 32, 59, 64, 65, 128, 200, 512, 1024]))
+        relu = bool(rng.randint(2))
+        x_wide = rng.standard_normal((rows, cin + 3)).astype(np.float32)
+        w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        scale = rng.uniform(0.5, 1.5, cout).astype(np.float32) if rng.randint(2) else None
+        shift = rng.standard_normal(cout).astype(np.float32) if rng.randint(2) else None
+        use_gb = bool(rng.randint(2))
+        rpg = pool if pool else int(rng.choice([1, rows]))
+        ngrp = rows // rpg if use_gb else 0
+        gb = rng.standard_normal((ngrp, cout)).astype(np.float32) if use_gb else None
+        x_dev = dev(x_wide, device)[:, 1:1 + cin]                      # a column slice: row stride cin + 3
+        y = x_wide[:, 1:1 + cin].astype(np.float64) @ w
+        if use_gb:
+            y = y + np.repeat(gb, rpg, 0)
+        y = y * (1.0 if scale is None else scale) + (0.0 if shift is None else shift)
+        if relu:
+            y = np.maximum(y, 0)
+        if pool:
+            y = y.reshape(groups, pool, cout).max(1)
+        wide = torch.full((y.shape[0], cout + 2), 7.0, device=device)
+        ops.shared_mlp(x_dev, dev(w, device), None if scale is None else dev(scale, device),
+                       None if shift is None else dev(shift, device), relu=relu, pool_rows=pool,
+                       group_bias=None if gb is None else dev(gb, device), rows_per_group=rpg if use_gb else 0,
+                       out=wide[:, 1:1 + cout])
+        tag = (trial, rows, cin, cout, pool, relu, use_gb)
+        got = wide.cpu().numpy()
+        assert (got[:, 0] == 7).all() and (got[:, -1] == 7).all(), tag            # nothing written outside the slice
+        err = np.abs(got[:, 1:1 + cout] - y) / np.maximum(np.abs(y), np.sqrt(np.mean(y ** 2)) + 1e-30)
+        assert err.max() <= 1e-4, (tag, err.max())
