@@ -269,3 +269,47 @@ def test_bayes_frustum_blocks_and_single_sample(device, precision):
             assert torch.equal(a[k], b[k]), (chunk, k)
     one = whole.forward(dev(pc[:1], device), dev(oh[:1], device), 1, generator=g)
     assert one["box_output"].shape == (1, 1, 59) and torch.isfinite(one["box_output"]).all()
+
+
+def test_flipout_layer_random_shapes(device):
+    """Twenty seeded random Flipout layers: sign groups of 1, 7, 32, 128 or 256 rows (the
+    last two take the folded-weight mode), 1-3 samples per launch, odd channel counts,
+    optional per-group bias and fused pooling."""
+    from fpn import ops
+    rng = np.random.RandomState(31)
+    for trial in range(20):
+        rpg = int(rng.choice([1, 7, 32, 128, 256]))
+        groups = int(rng.randint(1, 6))
+        S = int(rng.choice([1, 2, 3]))
+        rows = groups * rpg
+        cin = int(rng.choice([3, 20, 64, 131, 259]))
+        cout = int(rng.choice([2, 40, 64, 130, 256]))
+        pool = rpg if (rpg in (32, 128, 256) and rng.randint(2)) else 0
+        use_gb = bool(rng.randint(2))
+        x = rng.standard_normal((S * rows, cin)).astype(np.float32)
+        w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        dw = (rng.standard_normal((S, cin, cout)) * 0.05).astype(np.float32)
+        si = rng.choice([-1.0, 1.0], (S * groups, cin)).astype(np.float32)
+        so = rng.choice([-1.0, 1.0], (S * groups, cout)).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32)
+        gb = rng.standard_normal((S * groups, cout)).astype(np.float32) if use_gb else None
+        relu = bool(rng.randint(2))
+        got = ops.shared_mlp_flipout(dev(x, device), dev(w, device), dev(dw, device), rows, dev(si, device),
+                                     dev(so, device), rpg, shift=dev(bias, device), relu=relu, pool_rows=pool,
+                                     group_bias=None if gb is None else dev(gb, device))
+        want = []
+        for s in range(S):
+            xs = x[s * rows:(s + 1) * rows].astype(np.float64)
+            sis = np.repeat(si[s * groups:(s + 1) * groups], rpg, 0)
+            sos = np.repeat(so[s * groups:(s + 1) * groups], rpg, 0)
+            y = xs @ w + ((xs * sis) @ dw[s].astype(np.float64)) * sos
+            if use_gb:
+                y = y + np.repeat(gb[s * groups:(s + 1) * groups], rpg, 0)
+            y = y + bias
+            if relu:
+                y = np.maximum(y, 0)
+            want.append(y.reshape(-1, pool, cout).max(1) if pool else y)
+        try:
+            close(got.cpu().numpy(), np.concatenate(want, 0), 1e-4)
+        except AssertionError as e:
+            raise AssertionError("trial %r: %s" % ((trial, rpg, groups, S, cin, cout, pool, use_gb, relu), e))
