@@ -22,6 +22,7 @@
 // fp32 GEMM only by summation order.
 #include <algorithm>
 #include <cstdint>
+#include <mutex>
 
 #include "fpn_common.h"
 
@@ -403,6 +404,35 @@ int launch_mlp(const MlpParams &p, hipStream_t st, unsigned samples = 1)
     return rc;
 }
 
+// Scratch of fpn_shared_mlp_static_f32: the per-row-block partial maxima of a layer that
+// pools more than 128 rows.  One copy per GPU, held until the process ends.  The array's
+// NAME is a host-side handle, not a device address: host code uses the per-device
+// address hipGetSymbolAddress returns (static_scratch()), never the name itself.
+static __device__ __align__(256) float scratch[FPN_STATIC_SCRATCH_BYTES / sizeof(float)];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_lock;
+float *g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// This device's copy of `scratch` (looked up once per device, with the device current).
+int static_scratch(float **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(FPN_E_LAUNCH, "shared_mlp_static: hipGetDevice: %s", hipGetErrorString(e));
+    FPN_REQUIRE(dev >= 0 && dev < kMaxDevices, "shared_mlp_static: device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(FPN_E_LAUNCH, "shared_mlp_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<float *>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return FPN_OK;
+}
+
 int check_common(const char *who, long rows, int cin, int cout, const float *x, int ldx, const float *w,
                  int pool_rows, const float *y, int ldy, const void *workspace, size_t workspace_bytes)
 {
@@ -466,6 +496,25 @@ int fpn_shared_mlp_f32(long rows, int cin, int cout, const float *x, int ldx, co
     p.relu = relu; p.pool_rows = pool_rows; p.y = y; p.ldy = ldy;
     p.partial = static_cast<float *>(workspace);
     return launch_mlp<kPlain>(p, as_stream(stream));
+}
+
+int fpn_shared_mlp_static_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w,
+                              const float *scale, const float *shift, const float *group_bias,
+                              int rows_per_group, int relu, int pool_rows, float *y, int ldy, void *stream)
+{
+    const size_t need = fpn_shared_mlp_workspace_bytes(rows, cout, pool_rows);
+    FPN_REQUIRE(need <= (size_t)FPN_STATIC_SCRATCH_BYTES,
+                "shared_mlp_static: rows=%ld cout=%d pool_rows=%d needs %zu bytes of scratch, the static buffer holds %zu "
+                "(use fpn_shared_mlp_f32 with a workspace)", rows, cout, pool_rows, need, (size_t)FPN_STATIC_SCRATCH_BYTES);
+    float *ws = nullptr;
+    if (need) {
+        int rc = static_scratch(&ws);
+        if (rc != FPN_OK) return rc;
+    }
+    // every slot of the partial-maxima table that the second kernel reads is written by
+    // the first one of the same call: nothing has to start at zero
+    return fpn_shared_mlp_f32(rows, cin, cout, x, ldx, w, scale, shift, group_bias, rows_per_group, relu,
+                              pool_rows, y, ldy, ws, need, stream);
 }
 
 int fpn_shared_mlp_flipout_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w_mean,

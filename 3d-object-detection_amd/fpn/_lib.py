@@ -15,7 +15,8 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
     else os.path.join(_HERE, "libfpn_hip.so")
 
 FPN_OK = 0
-ABI_VERSION = 6
+STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
+ABI_VERSION = 7
 
 
 class FpnError(RuntimeError):
@@ -44,6 +45,7 @@ SIGNATURES = {
     "fpn_three_nn_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_select_top_k": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fpn_shared_mlp_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
+    "fpn_shared_mlp_static_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "fpn_shared_mlp_flipout_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
                                    _vp, _i, _vp, _sz, _vp],
     "fpn_max_pool_rows": [_l, _i, _i, _vp, _i, _vp, _i, _vp],

@@ -176,6 +176,26 @@ int fpn_shared_mlp_f32(long rows, int cin, int cout, const float *x, int ldx, co
 size_t fpn_shared_mlp_workspace_bytes(long rows, int cout, int pool_rows);
 
 /*
+ * fpn_shared_mlp_f32 for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments
+ * minus the workspace, same kernels, same results bit for bit.  The partial maxima of a
+ * layer with pool_rows > 128 go to a buffer of FPN_STATIC_SCRATCH_BYTES that lives in the
+ * library's device image (one copy per GPU, held until the process ends) instead of a
+ * caller workspace; a call that would need more (fpn_shared_mlp_workspace_bytes(rows,
+ * cout, pool_rows) > FPN_STATIC_SCRATCH_BYTES) is refused with FPN_E_INVALID_ARG.  The
+ * call allocates and frees nothing.  All calls on one GPU share that GPU's buffer: calls
+ * that may overlap on one GPU (different streams or threads) race and must be ordered
+ * by the caller.  The buffer's address is looked up on the first call on each device
+ * (make that call outside graph capture).
+ * No counterpart in the reference (TensorFlow allocates every temporary there).
+ */
+#define FPN_STATIC_SCRATCH_BYTES (8u << 20)
+int fpn_shared_mlp_static_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w,
+                              const float *scale, const float *shift, const float *group_bias,
+                              int rows_per_group, int relu, int pool_rows, float *y, int ldy,
+                              void *stream);
+
+/*
  * y[g,:] = max over the pool_rows consecutive rows of group g of x (rows, ldx):
  * tf_util.max_pool2d with kernel [N,1] (models/tf_util.py:366-389) /
  * tf.reduce_max over the sample axis (models/pointnet_util.py:126,192) as a
