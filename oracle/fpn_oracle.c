@@ -10,7 +10,9 @@
  * above each function names the reference file and lines it follows.  The
  * restatement is pinned two ways (see tests/test_oracle_pinning.py):
  *   - against the reference's own CPU loops compiled from /root/reference into
- *     oracle/_ref (ball query, group, interpolate, selection sort);
+ *     oracle/_ref (ball query, group, interpolate, selection sort, and three_nn
+ *     through the stand-alone threenn_cpu of interpolate.cpp:21-64 run on origin
+ *     queries and on query-translated known sets);
  *   - against the one known-answer case the reference carries
  *     (selection_sort.cpp:65-94).
  * FPS and gather_point have no CPU code in the reference (GPU-only kernels):

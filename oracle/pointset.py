@@ -188,6 +188,40 @@ def ref_three_interpolate(points, idx, weight):
     return out
 
 
+def ref_three_nn_origin(xyz2, n=1):
+    """threenn_cpu of the reference's interpolate.cpp (:21-64) as it is: the three known
+    points of xyz2 (b,m,3) nearest to the ORIGIN (its distance ignores the queries), for n
+    queries per batch."""
+    xyz2, p2 = _f(xyz2)
+    b, m, _ = xyz2.shape
+    xyz1 = np.zeros((b, n, 3), np.float32)
+    dist = np.empty((b, n, 3), np.float32)
+    idx = np.empty((b, n, 3), np.int32)
+    with np.errstate(over="ignore"):
+        ref().ref_threenn_origin_cpu(b, n, m, xyz1.ctypes.data_as(_f32p), p2, dist.ctypes.data_as(_f32p),
+                                     idx.ctypes.data_as(_i32p))
+    return dist, idx
+
+
+def ref_three_nn(xyz1, xyz2):
+    """three_nn(xyz1, xyz2) computed by the reference's compiled threenn_cpu: for every
+    query the known set is translated by the query in fp32 (x2' = x2 - x1, one IEEE
+    subtraction per coordinate, done here by numpy), after which the reference's
+    x2'*x2'+y2'*y2'+z2'*z2' IS tf_interpolate.cpp:73's (x2-x1)*(x2-x1)+... and the rest of
+    the loop (double compare, 1e40 start, strict-< cascade) is the reference's own."""
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.empty((b, n, 3), np.float32)
+    idx = np.empty((b, n, 3), np.int32)
+    for i in range(b):
+        shifted = (xyz2[i][None, :, :] - xyz1[i][:, None, :]).astype(np.float32)   # (n,m,3): one "batch" per query
+        d, k = ref_three_nn_origin(shifted, 1)
+        dist[i], idx[i] = d[:, 0], k[:, 0]
+    return dist, idx
+
+
 def ref_select_top_k(k, dist):
     dist, pd = _f(dist)
     b, m, n = dist.shape

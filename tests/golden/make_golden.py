@@ -1,8 +1,10 @@
 """Generates tests/golden/pointset_golden.npz: small seeded inputs with the outputs of
 the REFERENCE's own CPU loops (compiled from /root/reference into oracle/_ref by
-oracle/Makefile) where the reference has CPU code, and of the restatement in
-oracle/fpn_oracle.c where it has none (FPS, gather_point, three_nn: marked
-*_restated).  Run in the build container only:
+oracle/Makefile) where the reference has CPU code (*_ref: ball query, group_point,
+three_interpolate, selection sort, and three_nn through the stand-alone threenn_cpu of
+interpolate.cpp run on query-translated known sets, see oracle/pointset.ref_three_nn),
+and of the restatement in oracle/fpn_oracle.c where it has none (FPS, gather_point:
+marked *_restated).  Run in the build container only:
 
     make -C oracle all ref && python tests/golden/make_golden.py
 
@@ -58,11 +60,40 @@ def main():
     for tag, (b, n, m, c) in {"a": (2, 128, 32, 16), "b": (1, 300, 5, 3), "c": (2, 64, 2, 7)}.items():
         x1, x2 = clouds(rng, b, n), clouds(rng, b, m)
         p2 = rng.standard_normal((b, m, c)).astype(np.float32)
-        d, i = O.three_nn(x1, x2)
+        d, i = O.ref_three_nn(x1, x2)
         w = O.fp_weights(d)
         g["ti_%s_xyz1" % tag], g["ti_%s_xyz2" % tag], g["ti_%s_points" % tag] = x1, x2, p2
-        g["ti_%s_dist_restated" % tag], g["ti_%s_idx_restated" % tag], g["ti_%s_weight" % tag] = d, i, w
+        g["ti_%s_dist_ref" % tag], g["ti_%s_idx_ref" % tag], g["ti_%s_weight" % tag] = d, i, w
         g["ti_%s_out_ref" % tag] = O.ref_three_interpolate(p2, i, w)
+    # three_nn: the reference's threenn_cpu (interpolate.cpp:21-64).  "origin*": called as
+    # it is, every query at the origin (its distance ignores xyz1); the others: through
+    # ref_three_nn (known set translated by each query in fp32).  m < 3, duplicates of
+    # known points, lattice coordinates (exact distance ties) and metre-scale frustums.
+    for tag, (b, n, m, kind) in {"origin_a": (3, 4, 128, "origin"), "origin_b": (2, 2, 2, "origin"),
+                                 "origin_c": (2, 1, 1, "origin"), "origin_ties": (2, 3, 60, "origin_lattice"),
+                                 "m1": (2, 40, 1, "cube"), "m2": (2, 40, 2, "cube"), "m5": (2, 70, 5, "cube"),
+                                 "m128": (2, 2048, 128, "cube"), "ties": (2, 300, 50, "lattice"),
+                                 "subset": (1, 512, 64, "subset"), "metres": (2, 256, 32, "metres")}.items():
+        if kind.startswith("origin"):
+            x2 = clouds(rng, b, m) - np.float32(0.5) if kind == "origin" else \
+                rng.randint(-2, 3, (b, m, 3)).astype(np.float32)
+            x1 = np.zeros((b, n, 3), np.float32)
+            d, i = O.ref_three_nn_origin(x2, n)
+        else:
+            if kind == "lattice":
+                x1 = rng.randint(0, 4, (b, n, 3)).astype(np.float32)
+                x2 = rng.randint(0, 4, (b, m, 3)).astype(np.float32)
+            elif kind == "subset":                      # known points are a subset of the queries (FP modules)
+                x1 = clouds(rng, b, n)
+                x2 = x1[:, rng.permutation(n)[:m]].copy()
+            elif kind == "metres":
+                x1 = (clouds(rng, b, n) * np.float32([8, 4, 58]) + np.float32([-4, -2, 2])).astype(np.float32)
+                x2 = x1[:, :m].copy() + (rng.random_sample((b, m, 3)) < 0.5).astype(np.float32) * np.float32(0.25)
+            else:
+                x1, x2 = clouds(rng, b, n), clouds(rng, b, m)
+            d, i = O.ref_three_nn(x1, x2)
+        g["tn_%s_xyz1" % tag], g["tn_%s_xyz2" % tag] = x1, x2
+        g["tn_%s_dist_ref" % tag], g["tn_%s_idx_ref" % tag] = d, i
     # selection sort: the reference's known-answer input (selection_sort.cpp:65-94) and
     # a tie-heavy random case, both through the reference's selection_sort_cpu
     kat = (10 - np.arange(16, dtype=np.float32)).reshape(2, 2, 4)

@@ -1,0 +1,172 @@
+"""The two workload configurations no other GPU test runs at their stated sizes:
+
+  * the Bayesian detector (models/FPointNet_Bayes.py:54-68,92,140-223) with THIRTY-TWO
+    Monte-Carlo samples per frustum, Flipout noise and Monte-Carlo dropout, 1024-point
+    frustums, fp32 and bf16: samples spread over the passes against the float64 textbook
+    Flipout oracle, then the ensemble statistics of that real output;
+  * the v2 topology (models/pointnet_util.py:86-228 composed as fpn/models/v2_config.json
+    says) in bf16 on 2048-point frustums against the float64 numpy oracle under the
+    stated bf16 bound, and a chunk of 1024 such frustums through the independence
+    property (a frustum's results do not depend on the rest of the batch, bit for bit).
+
+Flipout parity is unpinned by the reference (the arithmetic lives in
+tensorflow_probability, absent); the oracle is the published estimator with the same
+noise."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bayes_numpy as BN
+from oracle import pointnet_numpy as P
+from oracle import v1_numpy as V
+
+pytestmark = pytest.mark.gpu
+
+BF16_RTOL = 4e-2     # the stated looser bound of the bf16 matrix path (tests/test_gpu_bf16.py)
+FP32_RTOL = 1e-3
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def scaled_err(got, want):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    s = np.sqrt(np.mean(want ** 2)) + 1e-30
+    return float((np.abs(got - want) / np.maximum(np.abs(want), s)).max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bayes_thirty_two_samples(device, precision):
+    from fpn import bayes, synthetic, uncertainty, variables
+    B, N, S = 6, 1024, 32
+    st = variables.VariableStore(device, seed=8)
+    bp = bayes.BayesPlan(st, 3, mc_dropout=True, precision=precision)
+    for k in list(st.keys()):
+        if k.endswith("/biases"):
+            st[k] = torch.randn(st[k].shape) * 0.1
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=21)
+    g = torch.Generator(device=device)
+    g.manual_seed(17)
+    noise = bp.sample_noise(S, B, g, N)
+    ep = bp.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+    assert ep["mask_logits"].shape == (S, B, N, 2) and ep["box_output"].shape == (S, B, 59)
+    for k in ("mask_logits", "box_output", "stage1_center"):
+        assert torch.isfinite(ep[k]).all(), k
+    bits = noise["dropout"].cpu().numpy()
+    params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
+    pc64, oh64 = pc.astype(np.float64), oh.astype(np.float64)
+    rtol = FP32_RTOL if precision == "fp32" else BF16_RTOL
+    worst = {}
+    for s in (0, 5, 13, 22, 31):       # first, last and three in between
+        keep = ((bits[s][..., None] >> np.arange(32)) & 1).reshape(B, N, 128).astype(bool)
+        nz = {}
+        for k, v in noise.items():
+            if k == "dropout":
+                continue
+            sigma = torch.nn.functional.softplus(st[k + "/rho"]) + np.finfo(np.float32).eps
+            nz[k] = ((sigma * v[0][s]).cpu().numpy().astype(np.float64), v[1][s].cpu().numpy().astype(np.float64),
+                     v[2][s].cpu().numpy().astype(np.float64))
+        want = BN.forward_sample(pc64, oh64, params, nz, dropout_keep=keep)
+        worst["mask_logits"] = max(worst.get("mask_logits", 0),
+                                   scaled_err(ep["mask_logits"][s].cpu().numpy(), want["mask_logits"]))
+        mask = ep["mask"][s].cpu().numpy()
+        # a point may flip only where the two logits agree within the bound
+        flips = mask != want["mask"]
+        if flips.any():
+            gap = np.abs(want["mask_logits"][..., 0] - want["mask_logits"][..., 1])[flips]
+            assert gap.max() <= 2 * rtol * np.sqrt(np.mean(want["mask_logits"] ** 2)), (s, gap.max())
+        want = BN.forward_sample(pc64, oh64, params, nz, mask_override=mask, dropout_keep=keep)
+        np.testing.assert_array_equal(ep["object_point_indices"][s].cpu().numpy(), want["object_point_indices"])
+        for k in ("center_delta", "stage1_center", "box_output", "center"):
+            worst[k] = max(worst.get(k, 0), scaled_err(ep[k][s].cpu().numpy(), want[k]))
+    print("Bayes S=32 %s scaled errors:" % precision, {k: "%.2e" % v for k, v in worst.items()})
+    assert max(worst.values()) <= rtol, worst
+    # all 32 samples differ (fresh weights and dropout bits per sample)
+    flat = ep["box_output"].reshape(S, -1)
+    assert len({tuple(r.tolist()) for r in flat.cpu()}) == S
+    # ensemble statistics of the network's own 32 samples
+    stats = uncertainty.mc_statistics(ep["box_output"].contiguous(), ep["stage1_center"].contiguous())
+    got = {k: v.cpu().numpy() for k, v in uncertainty.unpack(stats).items()}
+    want = BN.mc_statistics(ep["box_output"].cpu().numpy(), ep["stage1_center"].cpu().numpy())
+    for k in want:
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-5, atol=2e-5, err_msg=k)
+    assert (got["total_variance"] > 0).all()
+
+
+def _v2_store(device, pc, one_hot, seed=7):
+    from fpn import variables
+    from fpn.models import frustum_pointnets_v2 as M2
+    st = variables.VariableStore(device, seed=seed)
+    with variables.use_store(st):
+        M2.get_model(dev(pc[:1], device), dev(one_hot[:1], device), False)      # creates the variables
+    st.randomize_batch_norm(seed + 1)
+    return st
+
+
+def _v2_forward(device, st, pc, one_hot, precision):
+    from fpn import pointnet_util, variables
+    from fpn.models import frustum_pointnets_v2 as M2
+    old = pointnet_util.SA_PRECISION
+    pointnet_util.SA_PRECISION = precision
+    try:
+        with variables.use_store(st):
+            return M2.get_model(dev(pc, device), dev(one_hot, device), False)
+    finally:
+        pointnet_util.SA_PRECISION = old
+
+
+def test_v2_bf16_2048_points_against_float64_oracle(device):
+    from fpn import synthetic
+    from fpn.models import frustum_pointnets_v2 as M2
+    b, n = 4, 2048
+    pc, one_hot = synthetic.make_frustums(b, n, 4, seed=12)
+    pc[..., :3] *= 0.05      # bring the metric frustum into the radius range of the SA modules
+    st = _v2_store(device, pc, one_hot)
+    ep = _v2_forward(device, st, pc, one_hot, "bf16")
+    assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernels not taken"
+    params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
+    pc64, oh64 = pc.astype(np.float64), one_hot.astype(np.float64)
+    worst = {}
+    # sampling and grouping indices depend on coordinates only (fp32 on both sides)
+    logits = P.v2_instance_seg(pc, one_hot, params, M2.CONFIG, dtype=np.float64)
+    worst["mask_logits"] = scaled_err(ep["mask_logits"].cpu().numpy(), logits)
+    mask = ep["mask"].cpu().numpy()
+    obj, mean, _, idx = V.point_cloud_masking(pc, logits, mask_override=mask)
+    np.testing.assert_array_equal(ep["object_point_indices"].cpu().numpy(), idx)
+    delta = V.center_regression_net(obj.astype(np.float64), oh64, params, dtype=np.float64)
+    worst["center_delta"] = scaled_err(ep["center_delta"].cpu().numpy(), delta)
+    # the box net samples (obj - delta): give the oracle the GPU's delta so that rounding
+    # differences in delta cannot change the sampled set
+    gdelta = ep["center_delta"].cpu().numpy()
+    out = P.v2_box_estimation(obj - gdelta[:, None, :], one_hot, params, M2.CONFIG, dtype=np.float64)
+    worst["box_output"] = scaled_err(ep["box_output"].cpu().numpy(), out)
+    print("v2 bf16 scaled errors:", {k: "%.2e" % v for k, v in worst.items()})
+    assert max(worst.values()) <= BF16_RTOL, worst
+    assert worst["mask_logits"] > 1e-5, "suspiciously exact: is the bf16 path running?"
+    assert ep["center"].shape == (b, 3) and ep["size_residuals"].shape == (b, 8, 3)
+
+
+def test_v2_bf16_chunk_of_1024_frustums_properties(device):
+    """The unit of work of the streamed 200k-frustum scene set: one chunk of 1024 frustums x
+    2048 points in bf16.  Frustums are independent: a frustum's results inside the chunk
+    equal, bit for bit, its results in a batch of four; everything is finite; and those four
+    match the float64 oracle under the bf16 bound."""
+    from fpn import synthetic
+    from fpn.models import frustum_pointnets_v2 as M2
+    b, n = 1024, 2048
+    pc, one_hot = synthetic.make_frustums(b, n, 4, seed=3)
+    pc[..., :3] *= 0.05
+    st = _v2_store(device, pc, one_hot, seed=11)
+    full = _v2_forward(device, st, pc, one_hot, "bf16")
+    sub = [0, 333, 777, 1023]
+    alone = _v2_forward(device, st, pc[sub], one_hot[sub], "bf16")
+    for k in ("mask_logits", "mask", "object_point_indices", "center_delta", "box_output", "center"):
+        assert torch.equal(full[k][sub], alone[k]), k
+    assert torch.isfinite(full["mask_logits"]).all() and torch.isfinite(full["box_output"]).all()
+    assert full["mask_logits"].shape == (b, n, 2) and full["box_output"].shape == (b, 59)
+    params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
+    logits = P.v2_instance_seg(pc[sub], one_hot[sub], params, M2.CONFIG, dtype=np.float64)
+    err = scaled_err(alone["mask_logits"].cpu().numpy(), logits)
+    assert 1e-5 < err <= BF16_RTOL, err

@@ -5,9 +5,12 @@
     /root/reference (tests/golden/make_golden.py);
   * directly against those compiled loops on fresh random inputs wherever
     oracle/_ref/libfpn_ref.so is present.
-FPS, gather_point and three_nn have no CPU code in the reference (parity unpinned by
-reference tests); for them the golden file pins the restatement against regressions
-and the structural properties below are checked."""
+three_nn is pinned by the reference's stand-alone threenn_cpu (interpolate.cpp:21-64,
+whose distance ignores the queries): run as it is on origin queries, and on known sets
+translated by each query in fp32, where its distance is tf_interpolate.cpp:73's bit for
+bit (oracle/pointset.ref_three_nn).  FPS and gather_point have no CPU code in the
+reference (parity unpinned by reference tests); for them the golden file pins the
+restatement against regressions and the structural properties below are checked."""
 import os
 
 import numpy as np
@@ -52,11 +55,24 @@ def test_ball_query_and_group_golden(tag):
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_three_nn_interpolate_golden(tag):
     d, i = O.three_nn(GOLD["ti_%s_xyz1" % tag], GOLD["ti_%s_xyz2" % tag])
-    np.testing.assert_array_equal(i, GOLD["ti_%s_idx_restated" % tag])
-    np.testing.assert_array_equal(d, GOLD["ti_%s_dist_restated" % tag])
+    np.testing.assert_array_equal(i, GOLD["ti_%s_idx_ref" % tag])
+    np.testing.assert_array_equal(d, GOLD["ti_%s_dist_ref" % tag])
     w = O.fp_weights(d)
     np.testing.assert_array_equal(w, GOLD["ti_%s_weight" % tag])
     np.testing.assert_array_equal(O.three_interpolate(GOLD["ti_%s_points" % tag], i, w), GOLD["ti_%s_out_ref" % tag])
+
+
+TN_TAGS = ["origin_a", "origin_b", "origin_c", "origin_ties", "m1", "m2", "m5", "m128", "ties", "subset", "metres"]
+
+
+@pytest.mark.parametrize("tag", TN_TAGS)
+def test_three_nn_golden_reference_outputs(tag):
+    d, i = O.three_nn(GOLD["tn_%s_xyz1" % tag], GOLD["tn_%s_xyz2" % tag])
+    np.testing.assert_array_equal(i, GOLD["tn_%s_idx_ref" % tag])
+    np.testing.assert_array_equal(d, GOLD["tn_%s_dist_ref" % tag])
+    m = GOLD["tn_%s_xyz2" % tag].shape[1]
+    if m < 3:                                      # (float)1e40 = +inf, index 0 (interpolate.cpp:27-28)
+        assert np.isinf(d[..., m:]).all() and (i[..., m:] == 0).all()
 
 
 def test_three_nn_is_true_nearest():
@@ -121,6 +137,13 @@ def test_against_reference_loops_random():
         pts = rng.standard_normal((b, n, c)).astype(np.float32)
         np.testing.assert_array_equal(O.group_point(pts, idx), O.ref_group_point(pts, idx))
         d, i = O.three_nn(x1, x2)
+        rd, ri = O.ref_three_nn(x1, x2)
+        np.testing.assert_array_equal(i, ri)
+        np.testing.assert_array_equal(d, rd)
+        rd, ri = O.ref_three_nn_origin(x2, 2)
+        d0, i0 = O.three_nn(np.zeros((b, 2, 3), np.float32), x2)
+        np.testing.assert_array_equal(i0, ri)
+        np.testing.assert_array_equal(d0, rd)
         w = O.fp_weights(d)
         p2 = rng.standard_normal((b, m, c)).astype(np.float32)
         np.testing.assert_array_equal(O.three_interpolate(p2, i, w), O.ref_three_interpolate(p2, i, w))
