@@ -71,6 +71,21 @@ def gather_ragged(records, total, group=None):
     return torch.cat(keep, dim=0)
 
 
+STATS = 30      # width of the Monte-Carlo ensemble statistics table (fpn_mc_statistics)
+
+
+def gather_statistics(stats, total=None, group=None, out=None):
+    """Monte-Carlo ensembles: every rank keeps all samples of its own frustums, reduces them
+    to the (frustums, STATS) statistics table on its device and only that table travels:
+    one all-gather -> (total, STATS) on every rank in global frustum order.  `total`: size
+    of the global batch when the shards are ragged (shard_range blocks)."""
+    if stats.dim() != 2 or stats.shape[1] != STATS:
+        raise ValueError("expected a (frustums, %d) statistics table, got %s" % (STATS, tuple(stats.shape)))
+    if total is None:
+        return gather_results(stats.contiguous(), group, out)
+    return gather_ragged(stats.contiguous(), total, group)
+
+
 def _as_host_tensor(a):
     if isinstance(a, torch.Tensor):
         if a.device.type != "cpu":

@@ -43,15 +43,23 @@ def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
     return out
 
 
-def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
-    """Reference: pointnet_util.py:21-55.  Returns new_xyz (B,npoint,3), new_points
-    (B,npoint,nsample,3+C), idx (B,npoint,nsample), grouped_xyz (B,npoint,nsample,3)."""
-    xyz = xyz.contiguous()
+def _sample_and_query(npoint, radius, nsample, xyz, knn):
+    """The sampling half of sample_and_group (pointnet_util.py:39-43): new_xyz, idx."""
     new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
     if knn:
         _, idx = knn_point(nsample, xyz, new_xyz)
     else:
         idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+    return new_xyz, idx
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, sampled=None):
+    """Reference: pointnet_util.py:21-55.  Returns new_xyz (B,npoint,3), new_points
+    (B,npoint,nsample,3+C), idx (B,npoint,nsample), grouped_xyz (B,npoint,nsample,3).
+    `sampled` = (new_xyz, idx) already computed for these arguments (skips the sampling
+    and the neighbour search)."""
+    xyz = xyz.contiguous()
+    new_xyz, idx = sampled if sampled is not None else _sample_and_query(npoint, radius, nsample, xyz, knn)
     if points is not None and use_xyz:
         new_points = group_concat(xyz, new_xyz, points.contiguous(), idx, xyz_first=True)
         grouped_xyz = new_points[..., :3]
@@ -170,6 +178,12 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
     out2d.zero_()
     pad = plan["pad"]
     ldo = out2d.stride(0) if out2d.shape[0] > 1 else max(out2d.stride(0), out2d.shape[1])
+    obs = ops.launch_observer
+    tok = None
+    if obs is not None:       # algorithmic work: the unpadded layer widths
+        macs = (3 + cf) * widths[0] + widths[0] * widths[1] + widths[1] * widths[2]
+        tok = obs.begin("sa_chain%s[cf=%d,%d-%d-%d]" % ("_bf16" if "stream" in plan else "", cf, *widths),
+                        b * m * ns, 0, 0, macs=b * m * ns * macs)
     with torch.cuda.device(xyz.device):
         if "stream" in plan:
             _lib.check(_lib.load().fpn_sa_chain_bf16(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
@@ -180,6 +194,8 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
             _lib.check(_lib.load().fpn_sa_chain_f32(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
                                                     _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx), plan["table"],
                                                     _lib.ptr(out2d), ldo, int(widths[2]), _lib.stream_of(xyz)))
+    if obs is not None:
+        obs.end(tok)
     return True
 
 
@@ -206,14 +222,12 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx (B,npoint,nsample)."""
     tf_util._inference_only(is_training)
     with variables.variable_scope(scope):
+        sampled = None
         if not group_all and pooling == 'max' and mlp2 is None and FUSE_SA and (points is None or use_xyz):
             # grouping, MLP and max-pool in one kernel (:106-126) when the shape has one
             xyz = xyz.contiguous()
-            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
-            if knn:
-                _, idx = knn_point(nsample, xyz, new_xyz)
-            else:
-                idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            sampled = _sample_and_query(npoint, radius, nsample, xyz, knn)
+            new_xyz, idx = sampled
             pooled = torch.empty((xyz.shape[0] * npoint, mlp[-1]), dtype=torch.float32, device=xyz.device)
             if _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx.contiguous(), mlp,
                          'conv%d', bn, pooled, xyz_first=True):
@@ -222,8 +236,9 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             nsample = xyz.shape[1]
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
         else:
+            # (the fused kernel declined the shape: its samples and ball indices are reused)
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points,
-                                                                     knn, use_xyz)
+                                                                     knn, use_xyz, sampled=sampled)
         b, m, ns, c = new_points.shape
         x2d = new_points.contiguous().reshape(b * m * ns, c)
         if pooling == 'max':
@@ -357,6 +372,9 @@ def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, 
     logits = torch.empty((b, n, 2), dtype=torch.float32, device=xyz1.device)
     xb = None if points1 is None else points1.contiguous()
     lib = _lib.load()
+    obs = ops.launch_observer
+    tok = obs.begin("fp_head_chain_bf16" if "stream" in plan else "fp_head_chain", rows, 0, 0,
+                    macs=rows * ((128 + cb) * 128 + 2 * 128 * 128 + 128 * 2)) if obs is not None else None
     with torch.cuda.device(xyz1.device):
         if "stream" in plan:
             _lib.check(lib.fpn_fp_head_chain_bf16(rows, 128, cb, _lib.ptr(interpolated), _lib.ptr(xb),
@@ -365,4 +383,6 @@ def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, 
         else:
             _lib.check(lib.fpn_fp_head_chain_f32(rows, 128, cb, _lib.ptr(interpolated), _lib.ptr(xb), plan["table"],
                                                  _lib.ptr(logits), _lib.stream_of(xyz1)))
+    if obs is not None:
+        obs.end(tok)
     return logits

@@ -15,13 +15,14 @@ _CLASS_SIZE = np.array([[3.88311640418, 1.62856739989, 1.52563191462],   # Car
                         [1.76282397, 0.59706367, 1.73698127]])          # Cyclist
 
 
-def make_frustums(batch, num_point, channels=4, seed=0):
-    """-> point_cloud (batch,num_point,channels) float32, one_hot (batch,3) float32."""
+def make_frustums(batch, num_point, channels=4, seed=0, first_index=0):
+    """-> point_cloud (batch,num_point,channels) float32, one_hot (batch,3) float32.
+    first_index: global index of the first frustum (its class is index % 3)."""
     rng = np.random.RandomState(seed)
     z = rng.uniform(2.0, 60.0, size=(batch, num_point)).astype(np.float32)
     xy = rng.standard_normal((batch, num_point, 2)).astype(np.float32) * (0.1 * z)[..., None]
     pc = np.concatenate([xy, z[..., None]], axis=2)
-    cls = np.arange(batch) % 3
+    cls = (np.arange(batch) + first_index) % 3
     n_obj = int(0.3 * num_point)
     centre_z = rng.uniform(5.0, 50.0, size=(batch,)).astype(np.float32)
     centre_xy = rng.standard_normal((batch, 2)).astype(np.float32) * (0.05 * centre_z)[:, None]
@@ -42,6 +43,20 @@ def make_frustums(batch, num_point, channels=4, seed=0):
         pc = np.concatenate([pc, extra], axis=2)
     one_hot = np.eye(3, dtype=np.float32)[cls]
     return np.ascontiguousarray(pc, dtype=np.float32), one_hot
+
+
+def make_frustums_range(lo, hi, num_point, channels=4, seed=0):
+    """Frustums lo..hi-1 of ONE global seeded set whose frustum i is drawn from its own
+    stream (seed, i): any rank can make exactly its shard of the set without making the
+    rest, and shards made by different ranks concatenate to the set a single process
+    makes.  Same distribution as make_frustums; one_hot[i] = eye(3)[i % 3] of the GLOBAL
+    index.  -> point_cloud (hi-lo,num_point,channels), one_hot (hi-lo,3)."""
+    pcs = np.empty((max(hi - lo, 0), num_point, channels), np.float32)
+    one_hot = np.empty((max(hi - lo, 0), 3), np.float32)
+    for i in range(lo, hi):
+        pc, oh = make_frustums(1, num_point, channels, seed=[int(seed), i], first_index=i)
+        pcs[i - lo], one_hot[i - lo] = pc[0], oh[0]
+    return pcs, one_hot
 
 
 def unit_cube(batch, n, seed=100):

@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
-"""Benchmark of the Frustum-PointNet v1 hot path on MI355X.
+"""Benchmark of the Frustum-PointNet hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W            (N > 1: starts N ranks itself)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one v1 inference pass (instance segmentation net -> masking -> T-Net ->
-box net) over a batch of synthetic frustums already resident in HBM, followed - on
-N > 1 - by the RCCL all-gather of the per-frustum result records.  Workload:
-BASELINE config 1, 1024 frustums x 1024 points x 4 channels per GPU, fp32 (weak
-scaling: every rank runs the same per-GPU batch).  Rank 0 prints ONE JSON line.
+One step = one inference pass over this rank's shard of ONE global seeded batch of
+synthetic frustums, resident in HBM, followed - on N > 1 - by the single RCCL all-gather
+of the per-frustum result records (weak scaling: every rank holds the same number of
+frustums).  Default workload: BASELINE config 1, v1 network, 1024 frustums x 1024 points x
+4 channels per GPU, fp32.  --config v2 / --config bayes run the other GPU configurations
+with the same protocol.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel,
+HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on this host's cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,7 +31,9 @@ import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 16x the fp32 rate (v_mfma_f32_32x32x16_bf16, 32 cycles / 16384 MAC)
-ALGO_GFLOP_PER_FRUSTUM = None   # filled from the layer table below
+PEAK_HBM_GBS = 8000.0           # MI355X HBM3E spec peak, GB/s
+
+REHEARSAL = os.environ.get("FPN_BENCH_BACKEND", "nccl") != "nccl"
 
 
 def algorithmic_macs_per_frustum(n, m=512, pc_channels=4):
@@ -39,9 +46,49 @@ def algorithmic_macs_per_frustum(n, m=512, pc_channels=4):
     return seg_pt * n + seg_fr + tnet + box
 
 
+# ---- launching --------------------------------------------------------------------
+
+def spawn_ranks(gpus):
+    """`bench.py --gpus N` started bare (no WORLD_SIZE in the environment): start N ranks,
+    one per GPU, as children of this process through torch.distributed.run and return its
+    exit status.  Nothing here touches a GPU (device_count() does not initialise one), so
+    the children are the only processes that do."""
+    if not REHEARSAL:
+        have = torch.cuda.device_count()
+        if have < gpus:
+            print("bench.py: --gpus %d but only %d GPU(s) are visible (FPN_BENCH_BACKEND=gloo rehearses the "
+                  "multi-rank control flow on fewer devices)" % (gpus, have), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def init_rank(local_rank, world):
+    """One process per GPU: bind the rank's device and join the RCCL job (backend "nccl").
+    FPN_BENCH_BACKEND=gloo is a rehearsal switch for a box with fewer GPUs than ranks: the
+    ranks then share the visible devices round-robin and gather through gloo - it checks
+    the multi-rank control flow, its timings mean nothing."""
+    index = local_rank % torch.cuda.device_count() if REHEARSAL else local_rank
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if REHEARSAL:
+            dist.init_process_group(os.environ["FPN_BENCH_BACKEND"])
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return dev
+
+
+# ---- timing ------------------------------------------------------------------------
+
 class KernelTimer:
-    """HIP-event timer around shared-MLP launches (events are recorded on the stream the
-    kernels are launched on: torch's current stream).  `only`: names to time (the rest
+    """HIP-event timer around the fused-kernel launches (events are recorded on the stream
+    the kernels are launched on: torch's current stream).  `only`: names to time (the rest
     pass untouched: a pair of events around every launch costs the step about 2 %)."""
 
     def __init__(self, only=None):
@@ -73,57 +120,213 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline(seconds=12.0):
-    """The numpy restatement of the v1 graph (oracle/v1_numpy.py) timed on this
-    host's cores on BASELINE config 0 batches (32 frustums x 1024 points), repeated
-    for about `seconds` of wall time."""
-    from fpn import plan, synthetic, variables
-    from oracle import v1_numpy as V
+def settle_steps(warmup):
+    """Untimed steps beyond the requested warm-up: the GPU's clocks take a few steps of
+    work to reach their sustained state (measured: 126 k frustums/s over the first three
+    steps after one warm-up step, 138 k from the fifth step on), so at least five untimed
+    steps always precede the timed region."""
+    return max(0, 5 - warmup)
+
+
+# ---- recorded HBM traffic ------------------------------------------------------------
+
+def pmc_kernel_prefix(obs_name):
+    """Observer name of a launch -> the prefix of its kernel's name in the rocprofv3 counter
+    summaries (tools/pmc_summary.py strips the namespace and the argument list)."""
+    fixed = {"v1_seg_tail": "seg_tail_reg_kernel", "v1_seg_head": "seg_head_reg_kernel",
+             "v1_obj_chain_box": "obj_chain_reg_kernel<true>", "v1_obj_chain_tnet": "obj_chain_reg_kernel<false>",
+             "v1_seg_tail_bf16": "seg_tail_bf16_kernel", "v1_seg_head_bf16": "seg_head_bf16_kernel",
+             "v1_obj_chain_box_bf16": "obj_chain_bf16_kernel<true", "v1_obj_chain_tnet_bf16": "obj_chain_bf16_kernel<false",
+             "fp_head_chain": "fp_head_reg_kernel", "fp_head_chain_bf16": "fp_head_bf16_kernel"}
+    if obs_name in fixed:
+        return fixed[obs_name]
+    if obs_name.startswith("sa_chain"):
+        # "sa_chain[_bf16][cf=C,w1-w2-w3]" -> template arguments <cf/32, padded widths / 32>
+        inside = obs_name[obs_name.index("[") + 1:-1]
+        cf_s, widths = inside.split(",")
+        cf = int(cf_s[3:])
+        w = [int(v) for v in widths.split("-")]
+        up = lambda v, q: (v + q - 1) // q * q        # noqa: E731
+        targs = "%d, %d, %d, %d" % (cf // 32 if cf >= 32 else 0, up(w[0], 64) // 32, up(w[1], 64) // 32, up(w[2], 128) // 32)
+        return ("sa_chain_bf16_kernel<%s," if "_bf16" in obs_name else "sa_chain_kernel<%s>") % targs
+    return None
+
+
+def measured_traffic(obs_name, workload):
+    """HBM bytes per launch of the kernel behind `obs_name` from the newest committed
+    rocprofv3 PMC summary OF THIS WORKLOAD that holds the kernel (profiles/*_pmc_traffic.json,
+    made by tools/pmc_summary.py from separate FETCH_SIZE and WRITE_SIZE passes over this same
+    command).  Counters cannot be read from inside the timed process, so this is a recorded
+    measurement: (None, None) when no summary of the workload holds the kernel."""
+    import glob
+    prefix = pmc_kernel_prefix(obs_name)
+    if prefix is None or workload is None:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        # summaries written before the workload tag existed: plain kernel names = the headline workload
+        tag = d.get("workload") or ("v1_f32_1024x1024" if not any(" @ " in k for k in d["kernels"]) else None)
+        if tag != workload:
+            continue
+        hits = [v for k, v in d["kernels"].items() if k.split(" @ ")[0].startswith(prefix)]
+        n = sum(v["launches_sampled"] for v in hits)
+        if n:
+            return sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in hits) / n, os.path.basename(path)
+    return None, None
+
+
+# ---- CPU baselines (the oracle, timed on this host) ------------------------------------
+
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = 1
-    st = variables.VariableStore("cpu", seed=1)
-    plan.init_variables(st, 4, True)
-    st.randomize_batch_norm(2)
-    params = st.numpy()
-    pc, one_hot = synthetic.make_frustums(32, 1024, 4, seed=0)
-    V.get_model(pc, one_hot, params)  # warm-up
+    return model, int(threads)
+
+
+def _timed_loop(fn, units_per_call, seconds):
+    fn()            # warm-up
     t0 = time.perf_counter()
     done = 0
     while time.perf_counter() - t0 < seconds:
-        V.get_model(pc, one_hot, params)
-        done += 32
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frustums/s", "cores": int(threads), "kind": "port",
-            "sample": "numpy fp32 restatement of v1 get_model, %d frustums x 1024 pts in batches of 32 (%.1f s)"
-                      % (done, dt)}
+        fn()
+        done += units_per_call
+    return done / (time.perf_counter() - t0), done
 
 
-PEAK_HBM_GBS = 8000.0   # MI355X HBM3E spec peak, GB/s
+def cpu_baseline(kind, seconds=8.0, samples=32, params=None):
+    """The numpy restatement of the workload's graph (oracle/) timed on this host: once on
+    all the threads numpy's BLAS pool has (`value`, `cores`) and once on one thread
+    (`one_thread`).  A bounded sample of the same workload: small batches repeated for
+    about `seconds` per measurement."""
+    import numpy as np
+    from fpn import synthetic, variables
+    model, threads = cpu_info()
+    if kind == "v1":
+        from fpn import plan
+        from oracle import v1_numpy as V
+        st = variables.VariableStore("cpu", seed=1)
+        plan.init_variables(st, 4, True)
+        st.randomize_batch_norm(2)
+        params = st.numpy()
+        pc, one_hot = synthetic.make_frustums_range(0, 32, 1024, 4, seed=0)
+        fn, units = (lambda: V.get_model(pc, one_hot, params)), 32
+        what = "numpy fp32 restatement of v1 get_model, batches of 32 frustums x 1024 pts"
+    elif kind == "v2":
+        from fpn.models import frustum_pointnets_v2 as M2
+        from oracle import pointnet_numpy as P
+        from oracle import v1_numpy as V
+        pc, one_hot = synthetic.make_frustums_range(0, 4, 2048, 4, seed=0)
+        # params: host copy of the GPU run's variables (the v2 layers create theirs on first use)
 
-# observer name of a launch -> kernel name in the rocprofv3 counter summaries
-PMC_KERNEL = {"v1_seg_tail": "seg_tail_reg_kernel", "v1_seg_head": "seg_head_reg_kernel",
-              "v1_obj_chain_box": "obj_chain_reg_kernel<true>", "v1_obj_chain_tnet": "obj_chain_reg_kernel<false>"}
+        def fn():
+            logits = P.v2_instance_seg(pc, one_hot, params, M2.CONFIG)
+            obj, mean, _, _ = V.point_cloud_masking(pc, logits)
+            delta = V.center_regression_net(obj, one_hot, params)
+            return P.v2_box_estimation(obj - delta[:, None, :], one_hot, params, M2.CONFIG)
+        units = 4
+        what = "numpy fp32 + C point-set oracle restatement of the v2 graph, batches of 4 frustums x 2048 pts"
+    else:
+        from fpn import bayes
+        from oracle import bayes_numpy as BN
+        st = variables.VariableStore("cpu", seed=1)
+        bayes.init_variables(st, 3)
+        params = st.numpy()
+        b = 8
+        pc, one_hot = synthetic.make_frustums_range(0, b, 1024, 3, seed=0)
+        rng = np.random.RandomState(0)
+        noise = {}
+        for scope, cin, cout, _, _ in plan_table(3):
+            if scope in bayes.PLAIN:
+                continue
+            sigma = np.log1p(np.exp(params[scope + "/rho"])) + bayes.FLIPOUT_EPS
+            noise[scope] = ((sigma * rng.standard_normal((cin, cout))).astype(np.float32),
+                            rng.choice([-1.0, 1.0], (b, cin)).astype(np.float32),
+                            rng.choice([-1.0, 1.0], (b, cout)).astype(np.float32))
+        keep = rng.random_sample((b, 1024, 128)) < 0.5
+        fn = lambda: BN.forward_sample(pc, one_hot, params, noise, dtype=np.float32, dropout_keep=keep)      # noqa: E731
+        units = b / float(samples)        # one sampled pass over 8 frustums = 8/S frustums' worth of an S-sample ensemble
+        what = "numpy fp32 textbook-Flipout restatement, sampled passes over 8 frustums x 1024 pts (%d passes per " \
+               "frustum make one unit)" % samples
+    many, done_many = _timed_loop(fn, units, seconds)
+    one = None
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            one, _ = _timed_loop(fn, units, seconds)
+    except Exception:
+        pass
+    return {"value": many, "unit": "frustums/s", "cores": threads, "kind": "port",
+            "one_thread": {"value": one, "cores": 1}, "cpu_model": model,
+            "sample": "%s, repeated for about %.0f s per measurement (%.1f units at %d threads); labelled "
+                      "reference-equivalent CPU path (restated), not TensorFlow" % (what, seconds, done_many, threads)}
 
 
-def measured_traffic(name, batch, points):
-    """HBM bytes per launch of kernel `name` from the newest committed rocprofv3 PMC
-    summary (profiles/*_pmc_traffic.json, made by tools/pmc_summary.py from separate
-    FETCH_SIZE and WRITE_SIZE passes over this same command at the default workload).
-    Counters cannot be read from inside the timed process, so this is a recorded
-    measurement; None when there is no summary or the workload is not the default."""
-    import glob
-    if (batch, points) != (1024, 1024) or name not in PMC_KERNEL:
-        return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        k = json.load(f)["kernels"].get(PMC_KERNEL[name])
-    return (k["hbm_bytes_per_launch"], os.path.basename(files[-1])) if k else (None, None)
+def plan_table(pc_channels):
+    from fpn import plan
+    return plan.layer_table(pc_channels)
 
+
+def pointset_cpu(seconds_per_op=1.0):
+    """The point-set operators on ONE host core at the shapes of `pointset_ops`: the scalar C
+    oracle (kind "port") and, where the reference's own stand-alone CPU loops were compiled
+    into oracle/_ref (ball query, group_point, three_interpolate), those too (kind
+    "reference").  4 frustums per call, repeated for about `seconds_per_op`."""
+    import numpy as np
+    from fpn import synthetic
+    from oracle import pointset as O
+    B, N, M, NS, C = 4, 2048, 128, 64, 64
+    xyz = synthetic.unit_cube(B, N)
+    rng = np.random.RandomState(0)
+    feat = rng.standard_normal((B, N, C)).astype(np.float32)
+    feat2 = rng.standard_normal((B, M, C)).astype(np.float32)
+    idx = O.farthest_point_sample(M, xyz)
+    new_xyz = O.gather_point(xyz, idx)
+    gi, _ = O.query_ball_point(0.4, NS, xyz, new_xyz)
+    d3, i3 = O.three_nn(xyz, new_xyz)
+    w3 = O.fp_weights(d3)
+    cases = {
+        "farthest_point_sample(2048->128)": (lambda: O.farthest_point_sample(M, xyz), None),
+        "gather_point(128)": (lambda: O.gather_point(xyz, idx), None),
+        "query_ball_point(2048,128,r0.4,ns64)": (lambda: O.query_ball_point(0.4, NS, xyz, new_xyz),
+                                                 lambda: O.ref_query_ball_point(0.4, NS, xyz, new_xyz)),
+        "group_point(c=64)": (lambda: O.group_point(feat, gi), lambda: O.ref_group_point(feat, gi)),
+        "three_nn(2048,128)": (lambda: O.three_nn(xyz, new_xyz), None),
+        "three_nn_interpolate(2048,128,c=64)": (
+            lambda: O.three_interpolate(feat2, *(lambda d, i: (i, O.fp_weights(d)))(*O.three_nn(xyz, new_xyz))),
+            None),
+        "three_interpolate(2048,128,c=64)": (lambda: O.three_interpolate(feat2, i3, w3),
+                                             lambda: O.ref_three_interpolate(feat2, i3, w3)),
+    }
+    out = {}
+    for name, (port, ref) in cases.items():
+        rate, _ = _timed_loop(port, B, seconds_per_op)
+        out[name] = {"port_frustums_per_s": rate}
+        if ref is not None and O.have_ref():
+            rate, _ = _timed_loop(ref, B, seconds_per_op)
+            out[name]["reference_frustums_per_s"] = rate
+    out["cores"] = 1
+    out["note"] = "one host core; port = oracle/fpn_oracle.c, reference = the reference's own CPU loops " \
+                  "(query_ball_point.cpp, interpolate.cpp) compiled into oracle/_ref"
+    return out
+
+
+# ---- point-set operator bandwidths ----------------------------------------------------
 
 def pointset_ops(dev, frustums=256, reps=20):
     """Achieved HBM GB/s of the point-set operators at the v2 shapes (2048 points per
@@ -171,155 +374,112 @@ def pointset_ops(dev, frustums=256, reps=20):
     return out
 
 
-def settle_steps(warmup):
-    """Untimed steps beyond the requested warm-up: the GPU's clocks take a few steps of
-    work to reach their sustained state (measured: 126 k frustums/s over the first three
-    steps after one warm-up step, 138 k from the fifth step on), so at least five untimed
-    steps always precede the timed region."""
-    return max(0, 5 - warmup)
+# ---- workloads --------------------------------------------------------------------------
+
+def build_v1(args, dev, rank, world):
+    from fpn import dist as fdist
+    from fpn import plan, synthetic, variables
+    st = variables.VariableStore(dev, seed=1)        # identical weights on every rank (seeded)
+    plan.init_variables(st, 4, True)
+    st.randomize_batch_norm(2)
+    bf16 = args.dtype == "bf16"
+    net = plan.V1Plan(st, 4, True, chunk_frustums=args.chunk or None, precision="bf16" if bf16 else "fp32")
+    b_local = args.batch or 1024
+    points = args.points or 1024
+    lo, hi = fdist.shard_range(world * b_local, rank, world)     # this rank's block of the global batch
+    pc_np, oh_np = synthetic.make_frustums_range(lo, hi, points, 4, seed=0)
+    pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
+    macs = algorithmic_macs_per_frustum(points)
+    return {
+        "step": lambda: fdist.pack_results(net.forward(pc, one_hot)),
+        "gather": "records", "frustums": b_local, "points": points, "cpu": "v1",
+        "metric": "frustums/sec (node) FPointNet v1 N=%d" % points,
+        "label": "Frustum PointNet v1 inference, %d frustums x %d pts x 4 ch per GPU, %s"
+                 % (b_local, points, "bf16 MFMA with fp32 accumulation (not the headline configuration, which is "
+                    "fp32)" if bf16 else "fp32 MFMA (BASELINE config 1)"),
+        "workload_tag": "v1_%s_%dx%d" % (args.dtype, b_local, points) if not args.chunk else None,
+        "extra_config": {"algorithmic_gflop_per_frustum": 2 * macs / 1e9},
+        "model_flops_per_frustum": 2.0 * macs,
+    }
 
 
-REHEARSAL = os.environ.get("FPN_BENCH_BACKEND", "nccl") != "nccl"
-
-
-def init_rank(local_rank, world):
-    """One process per GPU: bind the rank's device and join the RCCL job (backend "nccl").
-    FPN_BENCH_BACKEND=gloo is a rehearsal switch for a box with fewer GPUs than ranks: the
-    ranks then share the visible devices round-robin and gather through gloo - it checks
-    the multi-rank control flow, its timings mean nothing."""
-    rehearsal = REHEARSAL
-    index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
-    torch.cuda.set_device(index)
-    dev = torch.device("cuda", index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group(os.environ["FPN_BENCH_BACKEND"])
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-    return dev
-
-
-def side_config(args):
-    """The other GPU workloads BASELINE names, with the same timing protocol as the
-    headline one: --config v2 (PointNet++ variant: FPS + ball query + grouping + shared
-    MLPs + 3-NN interpolation, 2048 points) and --config bayes (Flipout v1, S sampled
-    passes per frustum + ensemble statistics).  One JSON line, no roofline object: these
-    are mixes of HBM-bound point-set kernels and MFMA layers, the per-operator
-    bandwidths are in the `pointset_ops` table of the default run."""
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dev = init_rank(local_rank, world)
+def build_v2(args, dev, rank, world):
     from fpn import dist as fdist
     from fpn import synthetic, variables
-    if args.config == "v2":
-        from fpn.models import frustum_pointnets_v2 as M2
-        b_local = args.batch or 256
-        points = args.points or 2048
-        pc_np, oh_np = synthetic.make_frustums(b_local, points, 4, seed=rank)
-        pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
-        st = variables.VariableStore(dev, seed=1)
-        if args.dtype == "bf16":
-            from fpn import pointnet_util
-            pointnet_util.SA_PRECISION = "bf16"       # the fused set-abstraction kernels
+    from fpn.models import frustum_pointnets_v2 as M2
+    b_local = args.batch or 256
+    points = args.points or 2048
+    lo, hi = fdist.shard_range(world * b_local, rank, world)
+    pc_np, oh_np = synthetic.make_frustums_range(lo, hi, points, 4, seed=0)
+    pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
+    st = variables.VariableStore(dev, seed=1)
+    if args.dtype == "bf16":
+        from fpn import pointnet_util
+        pointnet_util.SA_PRECISION = "bf16"       # the fused set-abstraction kernels
+    with variables.use_store(st):
+        M2.get_model(pc[:2], one_hot[:2], False)      # creates the variables
+    st.randomize_batch_norm(2)
+
+    def forward(pc_, oh_):
         with variables.use_store(st):
-            M2.get_model(pc[:2], one_hot[:2], False)      # creates the variables
-        st.randomize_batch_norm(2)
-
-        def step():
-            with variables.use_store(st):
-                return fdist.pack_results(M2.get_model(pc, one_hot, False))
-        label = "Frustum PointNet v2 (SA-MSG x2, SA, FP x3; box net SA x3) inference, %d frustums x %d pts x 4 ch " \
-                "per GPU, %s" % (b_local, points, "bf16 MFMA in the set-abstraction kernels, fp32 elsewhere"
-                                 if args.dtype == "bf16" else "fp32")
-        metric = "frustums/sec (node) FPointNet v2 N=%d" % points
-    else:
-        from fpn import bayes, uncertainty
-        b_local = args.batch or 128
-        points = args.points or 1024
-        pc_np, oh_np = synthetic.make_frustums(b_local, points, 3, seed=rank)
-        pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
-        st = variables.VariableStore(dev, seed=1)
-        bayes.init_variables(st, 3)
-        bp = bayes.BayesPlan(st, 3, mc_dropout=args.mc_dropout, precision="bf16" if args.dtype == "bf16" else "fp32")
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(7 + rank)
-
-        def step():
-            ep = bp.forward(pc, one_hot, args.samples, generator=gen)
-            return uncertainty.mc_statistics(ep["box_output"], ep["stage1_center"])
-        label = "Flipout Frustum PointNet v1, %d Monte-Carlo samples x %d frustums x %d pts per GPU, %s, " \
-                "ensemble statistics on device%s" % (args.samples, b_local, points,
-                                                     "bf16 MFMA in the convolution stacks (fp32 first layers, "
-                                                     "maxima, head and fully connected layers)"
-                                                     if args.dtype == "bf16" else "fp32",
-                                                     ", Monte-Carlo dropout before the head" if args.mc_dropout else "")
-        metric = "frustums/sec (node) FPointNet Bayes S=%d N=%d" % (args.samples, points)
-    gathered = None
+            return M2.get_model(pc_, oh_, False)
+    step = lambda: fdist.pack_results(forward(pc, one_hot))       # noqa: E731
+    label = "Frustum PointNet v2 (SA-MSG x2, SA, FP x3; box net SA x3) inference, %d frustums x %d pts x 4 ch " \
+            "per GPU, %s" % (b_local, points, "bf16 MFMA in the set-abstraction kernels, fp32 elsewhere"
+                             if args.dtype == "bf16" else "fp32")
+    per_step = b_local
     if args.graph:
         from fpn.graph import GraphedForward
-        if args.config == "v2":
-            def fwd(pc_, oh_):
-                with variables.use_store(st):
-                    return fdist.pack_results(M2.get_model(pc_, oh_, False))
-            graphed = GraphedForward(fwd, [pc, one_hot])
-            step = lambda: graphed(pc, one_hot)       # noqa: E731
+        graphed = GraphedForward(lambda p, o: fdist.pack_results(forward(p, o)), [pc, one_hot])
+        step = lambda: graphed(pc, one_hot)       # noqa: E731
         label += ", HIP-graph replay"
-    per_step = b_local
     if args.stream_total:
         # a scene set larger than a batch, resident in (pinned) HOST memory, streamed through
         # the model in chunks of b_local frustums with the copies on a second stream
-        if args.config != "v2":
-            raise SystemExit("--stream-total goes with --config v2")
         reps = (args.stream_total + b_local - 1) // b_local
         host_pc = pc.cpu().repeat(reps, 1, 1)[:args.stream_total].contiguous().pin_memory()
         host_oh = one_hot.cpu().repeat(reps, 1)[:args.stream_total].contiguous().pin_memory()
         per_step = args.stream_total
-
-        def fwd_ep(pc_, oh_):
-            with variables.use_store(st):
-                return M2.get_model(pc_, oh_, False)
-        step = lambda: fdist.run_streamed(fwd_ep, host_pc, host_oh, b_local, dev)       # noqa: E731
+        step = lambda: fdist.run_streamed(forward, host_pc, host_oh, b_local, dev)       # noqa: E731
         label += ", %d frustums per GPU streamed from pinned host memory in chunks of %d (host-to-device copies " \
                  "inside the timed region, overlapped with compute)" % (args.stream_total, b_local)
+    plain = not (args.graph or args.stream_total)
+    return {"step": step, "gather": "records", "frustums": per_step, "points": points, "cpu": "v2",
+            "metric": "frustums/sec (node) FPointNet v2 N=%d" % points, "label": label,
+            "workload_tag": "v2_%s_%dx%d" % (args.dtype, b_local, points) if plain else None,
+            "extra_config": {}, "model_flops_per_frustum": None, "params": st.numpy}
 
-    def full_step():
-        nonlocal gathered
-        rec = step()
-        if world > 1:
-            if gathered is None:
-                gathered = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=dev)
-            dist.all_gather_into_tensor(gathered, rec.contiguous())
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup + settle_steps(args.warmup)):
-        full_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full_step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    if rank == 0:
-        print(json.dumps({"metric": metric, "value": world * per_step * args.steps / dt, "unit": "frustums/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "settle_steps": settle_steps(args.warmup),
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None,
-                          "dtype": args.dtype,
-                          "data": "synthetic",
-                          "config": {"workload": label, "frustums_per_gpu": b_local, "points": points}}))
-    if world > 1:
-        dist.destroy_process_group()
+def build_bayes(args, dev, rank, world):
+    from fpn import bayes, synthetic, uncertainty, variables
+    from fpn import dist as fdist
+    b_local = args.batch or 128
+    points = args.points or 1024
+    lo, hi = fdist.shard_range(world * b_local, rank, world)
+    pc_np, oh_np = synthetic.make_frustums_range(lo, hi, points, 3, seed=0)
+    pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
+    st = variables.VariableStore(dev, seed=1)
+    bayes.init_variables(st, 3)
+    bp = bayes.BayesPlan(st, 3, mc_dropout=args.mc_dropout, precision="bf16" if args.dtype == "bf16" else "fp32")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7 + rank)          # the NOISE differs per rank (independent draws); the data is one global set
 
+    def step():
+        ep = bp.forward(pc, one_hot, args.samples, generator=gen)
+        return uncertainty.mc_statistics(ep["box_output"], ep["stage1_center"])
+    label = "Flipout Frustum PointNet v1, %d Monte-Carlo samples x %d frustums x %d pts per GPU, %s, " \
+            "ensemble statistics on device%s" % (args.samples, b_local, points,
+                                                 "bf16 MFMA in the convolution stacks (fp32 first layers, "
+                                                 "maxima, head and fully connected layers)"
+                                                 if args.dtype == "bf16" else "fp32",
+                                                 ", Monte-Carlo dropout before the head" if args.mc_dropout else "")
+    return {"step": step, "gather": "statistics", "frustums": b_local, "points": points, "cpu": "bayes",
+            "metric": "frustums/sec (node) FPointNet Bayes S=%d N=%d" % (args.samples, points), "label": label,
+            "workload_tag": "bayes_%s_S%d_%dx%d" % (args.dtype, args.samples, b_local, points),
+            "extra_config": {"samples": args.samples}, "model_flops_per_frustum": None}
+
+
+# ---- main ---------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
@@ -347,44 +507,40 @@ def main():
                     help="operand type of the layer-chain kernels' matrix products (accumulation is always fp32); "
                          "f32 is the headline configuration")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a HIP graph (side configs; removes the host launch overhead)")
+                    help="replay the step from a HIP graph (--config v2; removes the host launch overhead)")
     args = ap.parse_args()
-    if args.config != "v1":
-        return side_config(args)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.stream_total and args.config != "v2":
+        raise SystemExit("--stream-total goes with --config v2")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))         # this process never touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = init_rank(local_rank, world)
 
     from fpn import dist as fdist
-    from fpn import ops, plan, synthetic, variables
-
-    # identical weights on every rank (seeded); per-rank shard of one global tensor
-    st = variables.VariableStore(dev, seed=1)
-    plan.init_variables(st, 4, True)
-    st.randomize_batch_norm(2)
+    from fpn import ops
+    wl = {"v1": build_v1, "v2": build_v2, "bayes": build_bayes}[args.config](args, dev, rank, world)
+    step = wl["step"]
     bf16 = args.dtype == "bf16"
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    net = plan.V1Plan(st, 4, True, chunk_frustums=args.chunk or None, precision="bf16" if bf16 else "fp32")
-    b_local = args.batch or 1024
-    args.points = args.points or 1024
-    pc_np, oh_np = synthetic.make_frustums(b_local, args.points, 4, seed=rank)
-    pc = torch.from_numpy(pc_np).to(dev)
-    one_hot = torch.from_numpy(oh_np).to(dev)
-    gathered = torch.empty((world * b_local, fdist.RECORD), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = [None]
 
-    def step():
-        ep = net.forward(pc, one_hot)
-        rec = fdist.pack_results(ep)
+    def full_step():
+        rec = step()
         if world > 1:
             if REHEARSAL:       # gloo: collectives on host copies
-                fdist.gather_results(rec.cpu())
+                rec = rec.cpu()
+            elif gathered[0] is None:
+                gathered[0] = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=dev)
+            if wl["gather"] == "statistics":
+                fdist.gather_statistics(rec, out=gathered[0])
             else:
-                fdist.gather_results(rec, out=gathered)
-        return rec
+                fdist.gather_results(rec, out=gathered[0])
 
     def fence():
         if world > 1:
@@ -392,17 +548,26 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup + settle_steps(args.warmup)):
+        full_step()
+    # Which fused kernel takes the largest share of the step: one untimed step with HIP
+    # events around every fused launch.  Inside the timed region only that kernel is
+    # bracketed (event pairs around every launch would slow the measured step by ~2 %);
+    # the per-kernel table comes from three more steps after the timed region.
+    dominant = None
+    if not args.no_kernel_timer:
+        probe = KernelTimer()
+        ops.launch_observer = probe
         step()
-    # Inside the timed region only the dominant kernel (the segmentation tail, 43 % of the
-    # step) is bracketed by HIP events; the per-kernel table comes from three more steps
-    # after it, so that event pairs around every launch do not slow the measured step.
-    dominant = "v1_seg_tail_bf16" if bf16 else "v1_seg_tail"
-    timer = None if args.no_kernel_timer else KernelTimer(only=None if args.chunk else {dominant})
+        ops.launch_observer = None
+        agg = probe.summary()
+        if agg:
+            dominant = max(agg, key=lambda k: agg[k][2])
+    timer = KernelTimer(only={dominant}) if dominant else None
     ops.launch_observer = timer
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        full_step()
     fence()
     dt = time.perf_counter() - t0
     ops.launch_observer = None
@@ -411,58 +576,61 @@ def main():
         table = KernelTimer()
         ops.launch_observer = table
         for _ in range(3):
-            net.forward(pc, one_hot)
+            step()
         ops.launch_observer = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    macs = algorithmic_macs_per_frustum(args.points)
-    total_frustums = world * b_local * args.steps
-    value = total_frustums / dt
-    out = {
-        "metric": "frustums/sec (node) FPointNet v1 N=%d" % args.points,
-        "value": value, "unit": "frustums/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "settle_steps": settle_steps(args.warmup),
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "Frustum PointNet v1 inference, %d frustums x %d pts x 4 ch per GPU, %s"
-                               % (b_local, args.points, "bf16 MFMA with fp32 accumulation (not the headline "
-                                  "configuration, which is fp32)" if bf16 else "fp32 MFMA (BASELINE config 1)"),
-                   "frustums_per_gpu": b_local, "points": args.points,
-                   "algorithmic_gflop_per_frustum": 2 * macs / 1e9,
-                   "model_tflops": value * 2 * macs / 1e12,
-                   "model_frac_of_mfma_peak": value * 2 * macs / 1e12 / (peak * world),
-                   "parallelism": "frustum-sharded x%d, all_gather of %d-float records" % (world, fdist.RECORD)},
-    }
+    value = world * wl["frustums"] * args.steps / dt
+    config = {"workload": wl["label"], "frustums_per_gpu": wl["frustums"], "points": wl["points"],
+              "data": "shards of one global seeded batch (fpn.synthetic.make_frustums_range, seed 0)",
+              "parallelism": "frustum-sharded x%d, one all_gather of %s" % (
+                  world, "%d-float ensemble statistics" % fdist.STATS if wl["gather"] == "statistics"
+                  else "%d-float result records" % fdist.RECORD)}
+    config.update(wl["extra_config"])
+    config["workload_tag"] = wl["workload_tag"]
+    if wl["model_flops_per_frustum"]:
+        peak_model = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        config["model_tflops"] = value * wl["model_flops_per_frustum"] / 1e12
+        config["model_frac_of_mfma_peak"] = config["model_tflops"] / (peak_model * world)
+    out = {"metric": wl["metric"], "value": value, "unit": "frustums/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "settle_steps": settle_steps(args.warmup), "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+           "data": "synthetic", "config": config}
     if rank == 0:
         if timer is not None:
             agg = timer.summary()
             full = table.summary()
-            name = max(agg, key=lambda k: agg[k][2])
-            launches, flops, secs = agg[name]
+            launches, flops, secs = agg[dominant]
             ach = flops / secs / 1e12
             top = max(full, key=lambda k: full[k][2])
-            if top != name:      # the timed kernel must be the one that dominates the step
-                out["roofline_note"] = "largest share of the step: %s" % top
-            traffic, traffic_src = measured_traffic(name, b_local, args.points) if not args.chunk else (None, None)
+            if top != dominant:      # the timed kernel must be the one that dominates the step
+                out["roofline_note"] = "largest share of the step in the post-run table: %s" % top
+            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dominant else PEAK_FP32_MFMA_TFLOPS
+            traffic, traffic_src = measured_traffic(dominant, wl["workload_tag"])
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic,
-                               "traffic_source": traffic_src, "kernel": name,
+                               "traffic_source": traffic_src, "kernel": dominant,
                                "launches": launches, "avg_launch_ms": secs / launches * 1e3,
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,
                                "share_of_step_time": secs / dt}
-            out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3} for k, v in full.items()}
-            out["kernels_source"] = "3 steps after the timed region, HIP events around every launch"
-        if world == 1 and not args.no_pointset:
+            out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
+                                  "tflops": v[1] / v[2] / 1e12 if v[2] > 0 else None} for k, v in full.items()}
+            out["kernels_source"] = "3 steps after the timed region, HIP events around every fused launch"
+        if world == 1 and not args.no_pointset and args.config in ("v1", "v2"):
             # 256 frustums = one workgroup per CU for the per-frustum kernels (FPS, ball
             # query): latency-bound; 4096 frustums lets several workgroups share a CU
             out["pointset_ops"] = pointset_ops(dev)
             out["pointset_ops_4096_frustums"] = pointset_ops(dev, frustums=4096, reps=5)
+            if not args.no_cpu_baseline:
+                out["pointset_cpu"] = pointset_cpu()
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(wl["cpu"], samples=args.samples,
+                                               params=wl["params"]() if "params" in wl else None)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -34,7 +34,12 @@ def _worker(rank, world, port, total, out_dir):
     if total % world == 0:
         same = fdist.gather_results(rec)
         assert torch.equal(same, full)
-    torch.save({"full": full, "full_l": full_l}, os.path.join(out_dir, "rank%d.pt" % rank))
+    # Monte-Carlo ensembles: the per-frustum statistics tables are what travels
+    stats = ids[:, None] * 2 + torch.arange(fdist.STATS)[None] / 10.0
+    full_s = fdist.gather_statistics(stats, total)
+    if total % world == 0:
+        assert torch.equal(fdist.gather_statistics(stats), full_s)
+    torch.save({"full": full, "full_l": full_l, "full_s": full_s}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,6 +57,8 @@ def _run(total, tmp_path, port):
         np.testing.assert_array_equal(back["stage1_center"][:, 1].numpy(), np.arange(total) + 0.5)
         lg = fdist.unpack_results(o["full_l"], 4)["mask_logits"]
         assert lg.shape == (total, 4, 2) and torch.equal(lg[:, 0, 0], torch.arange(total, dtype=torch.float32))
+        want_s = torch.arange(total, dtype=torch.float32)[:, None] * 2 + torch.arange(fdist.STATS)[None] / 10.0
+        assert torch.equal(o["full_s"], want_s)
     assert torch.equal(outs[0]["full"], outs[1]["full"])
 
 

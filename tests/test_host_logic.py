@@ -157,3 +157,10 @@ def test_synthetic_frustums():
     assert len(np.unique(pc[0, :, :3], axis=0)) < 1024
     pc3, _ = synthetic.make_frustums(2, 2048, 3, seed=1)
     assert pc3.shape == (2, 2048, 3)
+    # one global seeded set, shardable: blocks made separately concatenate to the whole
+    whole, oh_w = synthetic.make_frustums_range(0, 10, 256, 4, seed=3)
+    parts = [synthetic.make_frustums_range(lo, hi, 256, 4, seed=3) for lo, hi in ((0, 3), (3, 6), (6, 9), (9, 10))]
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), whole)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), oh_w)
+    assert (oh_w.argmax(1) == np.arange(10) % 3).all() and not np.array_equal(whole[0], whole[3])
+    assert synthetic.make_frustums_range(4, 4, 64)[0].shape == (0, 64, 4)

@@ -3,7 +3,11 @@ launch and kernel.
 
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dirF> -- python3 bench.py ...
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d <dirW> -- python3 bench.py ...
-  python tools/pmc_summary.py <dirF> <dirW> [--by-grid] > profiles/<round>_pmc_traffic.json
+  python tools/pmc_summary.py <dirF> <dirW> [--by-grid] [--workload TAG] > profiles/<round>_pmc_traffic.json
+
+--workload TAG records which bench.py workload the passes ran (bench.py prints the tag it
+looks for as config.workload_tag, e.g. v1_f32_1024x1024): bench.py only quotes traffic
+from a summary of its own workload.
 
 --by-grid keeps launches of one kernel with different grid sizes apart (key "name @ grid
 size in threads"): for runs that launch a kernel at several problem sizes.
@@ -42,6 +46,7 @@ def short(name):
 def main():
     global BY_GRID
     BY_GRID = "--by-grid" in sys.argv[3:]
+    workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else None
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     kernels = {}
     for key in sorted(set(fetch) | set(write)):
@@ -53,7 +58,7 @@ def main():
         wr = 1024.0 * sum(w) / max(len(w), 1)
         kernels[short(name) + (" @ " + grid if BY_GRID else "")] = {"launches_sampled": max(len(f), len(w)), "fetch_bytes_raw": fr,
                                 "fetch_bytes": 2.0 * fr, "write_bytes": wr, "hbm_bytes_per_launch": 2.0 * fr + wr}
-    json.dump({"unit": "bytes per launch", "fetch_correction": "x2 (gfx950, 16 B/lane coalesced reads)",
+    json.dump({"unit": "bytes per launch", "workload": workload, "fetch_correction": "x2 (gfx950, 16 B/lane coalesced reads)",
                "kernels": kernels}, sys.stdout, indent=1)
     print()
 

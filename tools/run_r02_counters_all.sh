@@ -1,0 +1,10 @@
+#!/bin/bash
+# Counter + trace records of every bench.py workload (see tools/run_counters.sh).
+set -e
+cd $GRAFT_REPO_ROOT
+bash tools/run_counters.sh r02c_v1 v1_f32_1024x1024 --steps 40 > gpurun_out/r02c_v1.txt
+bash tools/run_counters.sh r02c_v2_f32 v2_f32_256x2048 --config v2 --steps 10 --no-pointset > gpurun_out/r02c_v2_f32.txt
+bash tools/run_counters.sh r02c_v2_bf16 v2_bf16_256x2048 --config v2 --dtype bf16 --steps 10 --no-pointset > gpurun_out/r02c_v2_bf16.txt
+bash tools/run_counters.sh r02c_bayes_f32 bayes_f32_S32_128x1024 --config bayes --steps 2 --warmup 1 > gpurun_out/r02c_bayes_f32.txt
+bash tools/run_counters.sh r02c_bayes_bf16 bayes_bf16_S32_128x1024 --config bayes --dtype bf16 --steps 2 --warmup 1 > gpurun_out/r02c_bayes_bf16.txt
+echo done
