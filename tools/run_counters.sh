@@ -23,6 +23,7 @@ cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $out/pmc_fetch $out/pmc_write --workload $wl > $out/pmc_traffic.json
 python tools/sq_summary.py $out/sq_a $out/sq_b --workload $wl > $out/sq.json
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+rm -rf $out/pmc_fetch $out/pmc_write $out/sq_a $out/sq_b $out/trace      # raw per-dispatch records: tens of MiB
 python - <<PY
 import json
 k = json.load(open("$out/sq.json"))["kernels"]
