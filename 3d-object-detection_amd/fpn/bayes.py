@@ -50,6 +50,17 @@ def unpack_keep_bits(bits):
     return ((bits.unsqueeze(-1) >> shifts) & 1).reshape(bits.shape[:-1] + (128,)).float()
 
 
+class Noise(dict):
+    """noise[scope] = (eps (S,cin,cout), sign_in (S,B,cin), sign_out (S,B,cout)) [+ "dropout"].
+    When drawn by BayesPlan.sample_noise the per-scope tensors are VIEWS into three shared
+    buffers (one generator call each): eps_all (S, E), the layers' perturbation draws back to
+    back (scope k at column offsets[k]); sign_all (S, B, W), the layers' input and output
+    signs back to back.  The chain path then scales all draws of a sample block by
+    softplus(rho) in one launch instead of one per layer."""
+    eps_all = None
+    offsets = None
+
+
 class BayesPlan:
     """S Monte-Carlo forward passes of the Flipout network."""
 
@@ -73,6 +84,7 @@ class BayesPlan:
         self.table = _plan.layer_table(pc_channels)
         self._ones = {}
         self._w6_glob = None
+        self._sig_all = None
 
     # ---- noise -------------------------------------------------------------
     def sample_noise(self, nsamples, batch, generator=None, points=None):
@@ -81,14 +93,23 @@ class BayesPlan:
         and, with mc_dropout, noise["dropout"] = (S,batch,points,4) int32 keep bits of
         conv9's 128 outputs (bit c of word j keeps channel 32j + c; rate 0.5)."""
         dev = self.store.device
-        noise = {}
-        for scope, cin, cout, _, _ in self.table:
-            if scope in PLAIN:
-                continue
-            eps = torch.randn((nsamples, cin, cout), device=dev, generator=generator)
-            si = torch.randint(0, 2, (nsamples, batch, cin), device=dev, generator=generator).float() * 2 - 1
-            so = torch.randint(0, 2, (nsamples, batch, cout), device=dev, generator=generator).float() * 2 - 1
-            noise[scope] = (eps, si, so)
+        noise = Noise()
+        flip = [(scope, cin, cout) for scope, cin, cout, _, _ in self.table if scope not in PLAIN]
+        up4 = lambda v: (v + 3) // 4 * 4          # noqa: E731  (every slot starts on a 16-byte boundary)
+        total_e = sum(up4(cin * cout) for _, cin, cout in flip)
+        total_w = sum(up4(cin) + up4(cout) for _, cin, cout in flip)
+        # one call per kind of draw: all layers' N(0,1) perturbations, all layers' +-1 signs
+        eps_all = torch.randn((nsamples, total_e), device=dev, generator=generator)
+        sign_all = torch.randint(0, 2, (nsamples, batch, total_w), device=dev, generator=generator,
+                                 dtype=torch.float32).mul_(2.0).sub_(1.0)
+        noise.eps_all, noise.offsets = eps_all, {}
+        e = w = 0
+        for scope, cin, cout in flip:
+            noise.offsets[scope] = e
+            noise[scope] = (eps_all[:, e:e + cin * cout].unflatten(1, (cin, cout)),
+                            sign_all[:, :, w:w + cin], sign_all[:, :, w + up4(cin):w + up4(cin) + cout])
+            e += up4(cin * cout)
+            w += up4(cin) + up4(cout)
         if self.mc_dropout:
             if points is None:
                 raise ValueError("sample_noise needs the number of points per frustum for the dropout mask")
@@ -99,6 +120,20 @@ class BayesPlan:
 
     def _sigma(self, scope):
         return torch.nn.functional.softplus(self.store[scope + "/rho"]) + FLIPOUT_EPS
+
+    def _sigma_all(self):
+        """softplus(rho) + eps of every Flipout layer, flattened back to back in table order
+        (the column order of Noise.eps_all); cached until the store's variables change."""
+        hit = self._sig_all
+        if hit is None or hit[0] != self.store.version:
+            parts = []
+            for scope, cin, cout, _, _ in self.table:
+                if scope not in PLAIN:
+                    parts.append(self.store[scope + "/rho"].reshape(-1))
+                    if (cin * cout) % 4:      # the slots of Noise.eps_all start on 16-byte boundaries
+                        parts.append(parts[-1].new_zeros(4 - (cin * cout) % 4))
+            hit = self._sig_all = (self.store.version, torch.nn.functional.softplus(torch.cat(parts)) + FLIPOUT_EPS)
+        return hit[1]
 
     # ---- layers --------------------------------------------------------------
     def _flip(self, x, scope, dw, si, so, rows_per_group, relu=True, pool_rows=0, out=None):
@@ -125,9 +160,10 @@ class BayesPlan:
         drop = noise.get("dropout") if self.mc_dropout else None
         if self.mc_dropout and drop is None:
             raise ValueError("mc_dropout needs noise['dropout'] (see sample_noise)")
+        shared = noise if isinstance(noise, Noise) and noise.eps_all is not None else None
         noise = {k: v for k, v in noise.items() if k != "dropout"}
         if self.chain and 3 <= c <= 8:
-            return self._forward_chain(point_cloud, one_hot_vec, nsamples, noise, drop)
+            return self._finish(self._forward_chain(point_cloud, one_hot_vec, nsamples, noise, drop, shared))
         chunk = self.chunk_frustums or self.default_chunk(n)
         per_sample = []
         for s in range(nsamples):
@@ -155,38 +191,56 @@ class BayesPlan:
     CHAIN_COPIES = 1024
     SAMPLE_BLOCK = 64
 
-    def _forward_chain(self, point_cloud, one_hot_vec, nsamples, noise, drop=None):
+    @staticmethod
+    def _finish(r):
+        """Derived end points from the per-pass results, once for all samples: (S,B,...)."""
+        s_, b_ = r["box_output"].shape[:2]
+        r["stage1_center"] = r["center_delta"] + r["mask_xyz_mean"]
+        flat = {}
+        model_util.parse_output_to_tensors(r["box_output"].reshape(s_ * b_, 59), flat)
+        for k, v in flat.items():
+            r[k] = v.reshape((s_, b_) + tuple(v.shape[1:]))
+        r["center"] = r["center_boxnet"] + r["stage1_center"]
+        return r
+
+    def _forward_chain(self, point_cloud, one_hot_vec, nsamples, noise, drop=None, shared=None):
         """All samples of a block of frustums stacked along the frustum axis: a pass of
         the chain kernels works on (samples x frustums) independent "frustum copies",
-        each with its own effective weights."""
+        each with its own effective weights.  Returns the per-pass results stacked to
+        (S,B,...): mask_logits, mask, object_point_indices, mask_xyz_mean, center_delta,
+        box_output (the derived end points are formed once at the end, _finish)."""
         b, n, c = point_cloud.shape
         budget = self.chunk_frustums or self.CHAIN_COPIES
-        sig = {k: self._sigma(k) for k in noise}
-        result = {}
-        if b == 0:       # an empty batch: the end points with zero frustums, nothing to launch
-            dev = point_cloud.device
-            z = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=dev)     # noqa: E731
-            m = model_util.NUM_OBJECT_POINT
-            ep = {"mask_logits": z(0, n, 2), "mask": z(0, n), "object_point_indices": z(0, m, dtype=torch.int32),
-                  "mask_xyz_mean": z(0, 3), "center_delta": z(0, 3), "stage1_center": z(0, 3), "box_output": z(0, 59)}
-            model_util.parse_output_to_tensors(ep["box_output"], ep)
-            ep["center"] = ep["center_boxnet"] + ep["stage1_center"]
-            return {k: v.new_empty((nsamples,) + tuple(v.shape)) for k, v in ep.items()}
+        dev = point_cloud.device
+        m = model_util.NUM_OBJECT_POINT
+        z = lambda *shape, dtype=torch.float32: torch.empty((nsamples, b) + shape, dtype=dtype, device=dev)   # noqa: E731
+        result = {"mask_logits": z(n, 2), "mask": z(n), "object_point_indices": z(m, dtype=torch.int32),
+                  "mask_xyz_mean": z(3), "center_delta": z(3), "box_output": z(59)}
+        if b == 0 or nsamples == 0:      # an empty batch: the end points with zero frustums, nothing to launch
+            return result
+        sig = None if shared is not None else {k: self._sigma(k) for k in noise}
         # the perturbations sigma * eps of a block of samples are formed once (one launch per
-        # layer and block, not per pass); a block holds at most SAMPLE_BLOCK samples x 9 MB
+        # block when the draws share a buffer, else one per layer), not per pass; a block holds
+        # at most SAMPLE_BLOCK samples x 9 MB
         for q0 in range(0, nsamples, self.SAMPLE_BLOCK):
             q1 = min(nsamples, q0 + self.SAMPLE_BLOCK)
-            dws = {k: sig[k] * v[0][q0:q1] for k, v in noise.items()}
+            if shared is not None:
+                dw_all = shared.eps_all[q0:q1] * self._sigma_all()
+                dws = {k: dw_all[:, shared.offsets[k]:shared.offsets[k] + v[0].shape[1] * v[0].shape[2]]
+                       .unflatten(1, tuple(v[0].shape[1:])) for k, v in noise.items()}
+            else:
+                dws = {k: sig[k] * v[0][q0:q1] for k, v in noise.items()}
             for lo in range(0, b, budget):
                 hi = min(b, lo + budget)
                 bb = hi - lo
-                whole = lo == 0 and hi == b              # (then the sign slices below are views)
+                whole = lo == 0 and hi == b              # (then the slices below are views)
                 group = max(1, budget // bb)             # samples per pass
                 pcs, ohs = point_cloud[lo:hi].contiguous(), one_hot_vec[lo:hi].contiguous()
                 rep = None
                 for s0 in range(q0, q1, group):
                     s1 = min(q1, s0 + group)
                     sp = s1 - s0
+                    direct = whole or sp == 1
                     nz = {k: (dws[k][s0 - q0:s1 - q0],
                               v[1][s0:s1].reshape(sp * bb, -1) if whole else v[1][s0:s1, lo:hi].reshape(sp * bb, -1),
                               v[2][s0:s1].reshape(sp * bb, -1) if whole else v[2][s0:s1, lo:hi].reshape(sp * bb, -1))
@@ -194,11 +248,16 @@ class BayesPlan:
                     if rep is None or rep[0] != sp:      # the repeated inputs are the same for every pass of a block
                         rep = (sp, pcs.repeat(sp, 1, 1) if sp > 1 else pcs, ohs.repeat(sp, 1) if sp > 1 else ohs)
                     dm = None if drop is None else drop[s0:s1, lo:hi].reshape(sp * bb * n, 4).contiguous()
-                    ep = self._forward_chunk_chain(rep[1], rep[2], nz, sp, dm)
-                    for k, v in ep.items():
-                        if k not in result:
-                            result[k] = torch.empty((nsamples, b) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-                        result[k][s0:s1, lo:hi] = v.reshape((sp, bb) + tuple(v.shape[1:]))
+                    # the pass writes straight into the result buffers where its copies are
+                    # contiguous there (the whole batch, or one sample of a frustum block)
+                    outs = None
+                    if direct:
+                        outs = {k: (v[s0:s1] if whole else v[s0, lo:hi]).reshape((sp * bb,) + tuple(v.shape[2:]))
+                                for k, v in result.items()}
+                    ep = self._forward_chunk_chain(rep[1], rep[2], nz, sp, dm, outs)
+                    if not direct:
+                        for k, v in ep.items():
+                            result[k][s0:s1, lo:hi] = v.reshape((sp, bb) + tuple(v.shape[1:]))
         return result
 
     def _eff(self, scope, nz, layout, rows=None):
@@ -207,7 +266,9 @@ class BayesPlan:
         dw, si, so = nz[scope]
         w = self.store[scope + "/weights"]
         if rows is not None:
-            w, dw, si = w[:rows], dw[:, :rows], si[:, :rows].contiguous()
+            w, dw, si = w[:rows], dw[:, :rows], si[:, :rows]
+            if si.stride(0) % 4:          # (the kernels read the signs in 16-byte groups)
+                si = si.contiguous()
         return ops.flipout_weights(w, dw, si, so, layout)
 
     def _chain_tensors(self, scopes, nz, layouts):
@@ -218,17 +279,21 @@ class BayesPlan:
             t += [self._eff(scope, nz, layout), self._one(bias.shape[0]), bias]
         return t
 
-    def _forward_chunk_chain(self, pc, one_hot, nz, samples, drop_mask=None):
+    def _forward_chunk_chain(self, pc, one_hot, nz, samples, drop_mask=None, outs=None):
         """pc (samples * frustums, n, c): the frustum block repeated once per sample;
-        nz[scope] = (dw (samples,cin,cout), sign_in (copies,cin), sign_out (copies,cout))."""
+        nz[scope] = (dw (samples,cin,cout), sign_in (copies,>=cin), sign_out (copies,cout)),
+        possibly strided views (sample stride of dw, row strides of the signs).  outs: where
+        to write the six results (dense (copies, ...) tensors), else they are allocated."""
         b, n, c = pc.shape
         dev = pc.device
         m = model_util.NUM_OBJECT_POINT
         st = self.store
+        outs = outs or {}
 
         def conv(x, scope, rpg, relu=True):        # fully connected Flipout layers: one row per copy
             dw, si, so = nz[scope]
-            return ops.shared_mlp_flipout(x, st[scope + "/weights"], dw, x.shape[0] // samples, si, so, rpg,
+            return ops.shared_mlp_flipout(x, st[scope + "/weights"], dw.contiguous(), x.shape[0] // samples,
+                                          si.contiguous(), so.contiguous(), rpg,
                                           scale=None, shift=st[scope + "/biases"], relu=relu)
 
         bf16 = self.precision == "bf16"
@@ -268,12 +333,15 @@ class BayesPlan:
         if self._w6_glob is None or self._w6_glob[0] != st.version:
             self._w6_glob = (st.version, w6[64:].contiguous())       # rows of the frustum-constant inputs
         gshift = ops.shared_mlp_flipout(gcat, self._w6_glob[1], dw6[:, 64:].contiguous(), b // samples,
-                                        si6[:, 64:].contiguous(), so6, 1, scale=None, shift=st["conv6/biases"],
-                                        relu=False)
-        logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
+                                        si6[:, 64:].contiguous(), so6.contiguous(), 1, scale=None,
+                                        shift=st["conv6/biases"], relu=False)
+        logits = outs.get("mask_logits")
+        if logits is None:
+            logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
         if bf16:
             ws, cv = streams(("conv7", "conv8", "conv9"),
-                             first=(w6[:64], dw6[:, :64], si6[:, :64].contiguous(), so6))
+                             first=(w6[:64], dw6[:, :64], si6[:, :64] if si6.stride(0) % 4 == 0 else si6[:, :64].contiguous(),
+                                    so6))
             tail = [st[k + "/biases"] for k in ("conv7", "conv8", "conv9")] + \
                 [self._eff("conv10", nz, 0), st["conv10/biases"]]
             ops.v1_seg_tail_bf16(point_feat, n, gshift, ws, ops.pointer_table(tail), logits, copy_vecs=cv,
@@ -287,7 +355,8 @@ class BayesPlan:
                             drop_mask=drop_mask)
         del point_feat, head, tail
 
-        mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
+        mask, mean, sel, obj = ops.mask_gather(pc, logits, m, mask=outs.get("mask"), mean=outs.get("mask_xyz_mean"),
+                                               sel=outs.get("object_point_indices"))
         obj2d = obj.reshape(b * m, 3)
 
         # T-Net (FPointNet_Bayes.py:120-137)
@@ -296,8 +365,8 @@ class BayesPlan:
         obj_chain(("conv-reg1-stage1", "conv-reg2-stage1", "conv-reg3-stage1"), False, None, tcat)
         t = conv(tcat, "fc1-stage1", 1)
         t = conv(t, "fc2-stage1", 1)
-        center_delta = self._plain(t, "fc3-stage1")
-        stage1_center = center_delta + mean
+        center_delta = ops.shared_mlp(t, st["fc3-stage1/weights"], None, st["fc3-stage1/biases"], relu=False,
+                                      out=outs.get("center_delta"))
 
         # box net (FPointNet_Bayes.py:99-117); the kernel subtracts center_delta on load
         bcat = torch.zeros((b, 512 + 3), dtype=torch.float32, device=dev)
@@ -305,13 +374,9 @@ class BayesPlan:
         obj_chain(("conv-reg1", "conv-reg2", "conv-reg3", "conv-reg4"), True, center_delta, bcat)
         t = conv(bcat, "fc1", 1)
         t = conv(t, "fc2", 1)
-        output = self._plain(t, "fc3")
-
-        ep = {"mask_logits": logits, "mask": mask, "object_point_indices": sel, "mask_xyz_mean": mean,
-              "center_delta": center_delta, "stage1_center": stage1_center, "box_output": output}
-        model_util.parse_output_to_tensors(output, ep)
-        ep["center"] = ep["center_boxnet"] + stage1_center
-        return ep
+        output = ops.shared_mlp(t, st["fc3/weights"], None, st["fc3/biases"], relu=False, out=outs.get("box_output"))
+        return {"mask_logits": logits, "mask": mask, "object_point_indices": sel, "mask_xyz_mean": mean,
+                "center_delta": center_delta, "box_output": output}
 
     def _forward_chunk(self, pc, one_hot, nz, drop=None):
         b, n, c = pc.shape

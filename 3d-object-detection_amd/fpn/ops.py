@@ -16,6 +16,28 @@ def mlp_kernel_name(cout):
     return "shared_mlp_128x128" if cout > 64 else ("shared_mlp_128x64" if cout > 32 else "shared_mlp_128x32")
 
 
+def _check_layer_operands(x, w, cin, cout, scale, shift, group_bias, groups, extra=()):
+    """A raw-pointer ABI reads whatever it is given: weights must be a dense float32
+    (cin,cout) matrix on x's device, the per-channel constants dense (cout,) vectors, a
+    per-group bias a dense (groups,cout) table; `extra`: (name, tensor, shape) triples."""
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError("x must be a float32 tensor on a ROCm device (got %s on %s)" % (x.dtype, x.device))
+    _lib.require_device_tensor("w", w, torch.float32, 2)
+    if tuple(w.shape) != (cin, cout):
+        raise ValueError("w has shape %s, expected (%d, %d)" % (tuple(w.shape), cin, cout))
+    named = [("scale", scale, (cout,)), ("shift", shift, (cout,))]
+    if group_bias is not None:
+        named.append(("group_bias", group_bias, (groups, cout)))
+    named += list(extra)
+    for name, t, shape in named:
+        if t is None:
+            continue
+        _lib.require_device_tensor(name, t, torch.float32, len(shape))
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    _lib.same_device(x, w, scale, shift, group_bias, *[t for _, t, _ in extra])
+
+
 def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=None,
                rows_per_group=0, out=None, cin=None):
     """One fused layer through fpn_shared_mlp_f32.
@@ -34,11 +56,16 @@ def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=
     cout = w.shape[1]
     if x.shape[1] < cin or w.shape[0] != cin:
         raise ValueError("x has %d columns, w is %s" % (x.shape[1], tuple(w.shape)))
+    if group_bias is not None and rows_per_group < 1:
+        raise ValueError("group_bias needs rows_per_group >= 1")
+    _check_layer_operands(x, w, cin, cout, scale, shift, group_bias,
+                          -(-rows // rows_per_group) if group_bias is not None else 0)
     rows_out = rows // pool_rows if pool_rows else rows
     if out is None:
         out = torch.empty((rows_out, cout), dtype=torch.float32, device=x.device)
-    if out.shape[0] != rows_out or out.shape[1] < cout or out.stride(1) != 1:
-        raise ValueError("out has shape %s, expected (%d, >=%d)" % (tuple(out.shape), rows_out, cout))
+    if out.shape[0] != rows_out or out.shape[1] < cout or out.stride(1) != 1 or out.dtype != torch.float32 \
+            or out.device != x.device:
+        raise ValueError("out has shape %s, expected float32 (%d, >=%d) on %s" % (tuple(out.shape), rows_out, cout, x.device))
     ldy = out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1])
     ws = None
     ws_bytes = lib.fpn_shared_mlp_workspace_bytes(rows, cout, pool_rows)
@@ -62,8 +89,19 @@ def shared_mlp_flipout(x, w_mean, w_delta, rows_per_sample, sign_in, sign_out, r
     w_mean (cin,cout), w_delta (S,cin,cout), sign_in (groups,cin), sign_out
     (groups,cout) with groups = rows / rows_per_group."""
     lib = _lib.load()
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D tensor with unit column stride")
     rows, ldx = x.shape[0], x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
     cin, cout = w_mean.shape
+    if x.shape[1] < cin:
+        raise ValueError("x has %d columns, w_mean is %s" % (x.shape[1], tuple(w_mean.shape)))
+    if rows_per_group < 1 or rows_per_sample < 1 or rows % rows_per_sample or rows_per_sample % rows_per_group:
+        raise ValueError("rows (%d) must split into samples of %d rows and those into groups of %d"
+                         % (rows, rows_per_sample, rows_per_group))
+    groups = rows // rows_per_group
+    _check_layer_operands(x, w_mean, cin, cout, scale, shift, group_bias, groups,
+                          extra=[("w_delta", w_delta, (rows // rows_per_sample, cin, cout)),
+                                 ("sign_in", sign_in, (groups, cin)), ("sign_out", sign_out, (groups, cout))])
     rows_out = rows // pool_rows if pool_rows else rows
     if out is None:
         out = torch.empty((rows_out, cout), dtype=torch.float32, device=x.device)
@@ -85,7 +123,11 @@ def shared_mlp_flipout(x, w_mean, w_delta, rows_per_sample, sign_in, sign_out, r
 def max_pool_rows(x, pool_rows, out=None):
     """x (rows, C) -> (rows/pool_rows, C): max over groups of consecutive rows,
     through fpn_max_pool_rows."""
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError("x must be a 2-D float32 tensor with unit column stride on a ROCm device")
     rows, c = x.shape
+    if pool_rows < 1 or rows % pool_rows:
+        raise ValueError("rows (%d) must be a multiple of pool_rows (%d)" % (rows, pool_rows))
     ldx = x.stride(0) if rows > 1 else max(x.stride(0), c)
     if out is None:
         out = torch.empty((rows // pool_rows, c), dtype=torch.float32, device=x.device)
@@ -294,16 +336,26 @@ def v1_obj_chain_bf16(obj2d, m, box, delta, wstream, consts, feat_max, copy_vecs
         obs.end(tok)
 
 
-def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True):
+def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True, mask=None, mean=None, sel=None):
     """point_cloud (B,N,C>=3), logits (B,N,2) -> mask (B,N), mean (B,3), sel
-    (B,npick) int32, obj (B,npick,3) through fpn_mask_gather."""
+    (B,npick) int32, obj (B,npick,3) through fpn_mask_gather.  mask / mean / sel: dense
+    tensors of those shapes to write into (allocated when None)."""
     _lib.require_device_tensor("point_cloud", point_cloud, torch.float32, 3)
     _lib.require_device_tensor("logits", logits, torch.float32, 3, 2)
     b, n, c = point_cloud.shape
     dev = point_cloud.device
-    mask = torch.empty((b, n), dtype=torch.float32, device=dev) if want_mask else None
-    mean = torch.empty((b, 3), dtype=torch.float32, device=dev)
-    sel = torch.empty((b, npick), dtype=torch.int32, device=dev) if want_sel else None
+    for name, t, dtype, shape in (("mask", mask, torch.float32, (b, n)), ("mean", mean, torch.float32, (b, 3)),
+                                  ("sel", sel, torch.int32, (b, npick))):
+        if t is not None:
+            _lib.require_device_tensor(name, t, dtype, 2)
+            if tuple(t.shape) != shape or t.device != dev:
+                raise ValueError("%s must be %s on %s, got %s on %s" % (name, shape, dev, tuple(t.shape), t.device))
+    if mask is None and want_mask:
+        mask = torch.empty((b, n), dtype=torch.float32, device=dev)
+    if mean is None:
+        mean = torch.empty((b, 3), dtype=torch.float32, device=dev)
+    if sel is None and want_sel:
+        sel = torch.empty((b, npick), dtype=torch.int32, device=dev)
     obj = torch.empty((b, npick, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.load().fpn_mask_gather(b, n, c, int(npick), _lib.ptr(point_cloud), _lib.ptr(logits),
