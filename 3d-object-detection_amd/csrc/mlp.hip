@@ -341,6 +341,187 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
     }
 }
 
+// ---------------------------------------------------------------------------
+// Few rows (fully connected layers: one row per frustum; the small feature-propagation
+// and group-all layers of the PointNet++ variant): 128-row tiles would leave most of
+// the chip idle and a K loop through LDS with a barrier per step leaves each
+// workgroup waiting on memory latency.  Here a workgroup owns a 32-row x 64-column
+// output tile and its four waves SPLIT K: wave w multiplies the w-th quarter of the
+// input channels, with both MFMA operands loaded straight from memory into registers
+// (activations: 16 bytes per lane, 4 consecutive channels of its row; weights: one dword
+// per lane and MFMA, a row of 32 consecutive columns) through a register ring three
+// K blocks deep - no LDS, no barrier inside the K loop.  The four partial tiles are then
+// summed through LDS in a fixed order (deterministic) and the usual epilogue runs on the
+// sum.  32 x 64 tiles give 256 workgroups for a 1024 x 512 layer.
+//   k order inside a block of 8 channels: lane half h takes channels 8j + 4h + i in
+//   step i, so a lane's four activation values are contiguous.
+// MODE kFlipoutTwoPass: a second accumulator takes (x * s_in) . dW; the epilogue adds it
+// times s_out.
+// ---------------------------------------------------------------------------
+constexpr int kFrRows = 32, kFrCols = 64, kFrRing = 3;
+
+template <int MODE>
+__global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams pin)
+{
+    static_assert(MODE == kPlain || MODE == kFlipoutTwoPass, "plain or two-product Flipout");
+    constexpr bool FLIP = MODE == kFlipoutTwoPass;
+    MlpParams p = pin;
+    if (FLIP) {
+        const long s = blockIdx.y;
+        p.x += s * pin.sx;
+        p.w_delta += s * pin.swd;
+        p.sign_in += s * pin.ssi;
+        p.sign_out += s * pin.sso;
+        if (p.group_bias) p.group_bias += s * pin.sgb;
+        p.y += s * pin.sy;
+    }
+    __shared__ float part[(FLIP ? 2 : 1) * 4 * kFrRows * (kFrCols + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ncb = (p.cout + kFrCols - 1) / kFrCols;
+    const long row0 = (long)(blockIdx.x / ncb) * kFrRows;
+    const int col0 = (int)(blockIdx.x % ncb) * kFrCols;
+    const int cin = p.cin, cout = p.cout;
+
+    // this wave's share of the input channels, in blocks of 8
+    const int nblk = (cin + 7) >> 3;
+    const int per = (nblk + 3) >> 2;
+    const int b0 = wave * per, b1 = min(nblk, b0 + per);
+
+    const long row = min(row0 + l31, p.rows - 1);             // (rows beyond the end repeat the last one, never stored)
+    const float *xrow = p.x + row * p.ldx;
+    const float *srow = FLIP ? p.sign_in + (row / p.rows_per_group) * cin : nullptr;
+    const int ca = min(col0 + l31, cout - 1), cb = min(col0 + 32 + l31, cout - 1);
+    const bool two = col0 + 32 < cout;                         // (uniform: the tile's second 32 columns exist)
+    const bool xvec = (p.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    const bool svec = FLIP && (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.sign_in) & 15) == 0);
+
+    struct Stage { float x[4], s[4], wa[4], wb[4], da[4], db[4]; };
+    Stage ring[kFrRing];
+    auto load = [&](Stage &st, int j) {
+        const int k = 8 * j + 4 * h;
+        if (k + 3 < cin) {
+            if (xvec) {
+                const float4 v = *reinterpret_cast<const float4 *>(xrow + k);
+                st.x[0] = v.x; st.x[1] = v.y; st.x[2] = v.z; st.x[3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st.x[i] = xrow[k + i];
+            }
+            if (FLIP) {
+                if (svec) {
+                    const float4 v = *reinterpret_cast<const float4 *>(srow + k);
+                    st.s[0] = v.x; st.s[1] = v.y; st.s[2] = v.z; st.s[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st.s[i] = srow[k + i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st.wa[i] = p.w[(long)(k + i) * cout + ca];
+                st.wb[i] = two ? p.w[(long)(k + i) * cout + cb] : 0.f;
+                if (FLIP) {
+                    st.da[i] = p.w_delta[(long)(k + i) * cout + ca];
+                    st.db[i] = two ? p.w_delta[(long)(k + i) * cout + cb] : 0.f;
+                }
+            }
+        } else {       // the block that holds the last channel: zero activations beyond it, clamped weight rows
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = k + i < cin;
+                const int kk = min(k + i, cin - 1);
+                st.x[i] = ok ? xrow[kk] : 0.f;
+                if (FLIP) st.s[i] = ok ? srow[kk] : 0.f;
+                st.wa[i] = p.w[(long)kk * cout + ca];
+                st.wb[i] = two ? p.w[(long)kk * cout + cb] : 0.f;
+                if (FLIP) {
+                    st.da[i] = p.w_delta[(long)kk * cout + ca];
+                    st.db[i] = two ? p.w_delta[(long)kk * cout + cb] : 0.f;
+                }
+            }
+        }
+    };
+    floatx16 acc[2], accd[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; accd[0][r] = 0.f; accd[1][r] = 0.f; }
+    auto step = [&](const Stage &st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(st.x[i], st.wa[i], acc[0], 0, 0, 0);
+            if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(st.x[i], st.wb[i], acc[1], 0, 0, 0);
+        }
+        if (FLIP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xs = st.x[i] * st.s[i];
+                accd[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs, st.da[i], accd[0], 0, 0, 0);
+                if (two) accd[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs, st.db[i], accd[1], 0, 0, 0);
+            }
+        }
+    };
+    // ring of kFrRing K blocks; the stages are fenced so that the scheduler keeps a refill
+    // behind the use of the stage it overwrites and ahead of the next stage's use
+    const int n = b1 - b0;
+    const int npipe = n > 0 ? (n / kFrRing) * kFrRing : 0;
+    if (npipe > 0) {
+#pragma unroll
+        for (int s = 0; s < kFrRing; ++s) load(ring[s], b0 + s);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int j0 = 0; j0 < npipe; j0 += kFrRing) {
+#pragma unroll
+            for (int s = 0; s < kFrRing; ++s) {
+                step(ring[s]);
+                __builtin_amdgcn_sched_barrier(0);
+                load(ring[s], b0 + min(j0 + s + kFrRing, npipe - 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    for (int j = npipe; j < n; ++j) {
+        load(ring[0], b0 + j);
+        step(ring[0]);
+    }
+
+    // partial tiles -> LDS: register r of tile u holds row (r&3) + 8(r>>2) + 4h, column 32u + l31
+    constexpr int LD = kFrCols + 1;
+    float *mine = part + wave * kFrRows * LD;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            mine[rr * LD + 32 * u + l31] = acc[u][r];
+            if (FLIP) mine[4 * kFrRows * LD + rr * LD + 32 * u + l31] = accd[u][r];
+        }
+    __syncthreads();
+    // sum of the four waves' partial tiles in wave order, then the epilogue; a thread owns
+    // one column and eight rows
+    const int c = tid & 63, col = col0 + c;
+    if (col >= cout) return;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int rr = (tid >> 6) + 4 * i;
+        const long rw = row0 + rr;
+        if (rw >= p.rows) break;
+        float v = part[rr * LD + c];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += part[(w * kFrRows + rr) * LD + c];
+        if (FLIP) {
+            float d = part[(4 * kFrRows + rr) * LD + c];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) d += part[((4 + w) * kFrRows + rr) * LD + c];
+            v += d * p.sign_out[(rw / p.rows_per_group) * cout + col];
+        }
+        if (p.group_bias) v += p.group_bias[(rw / p.rows_per_group) * cout + col];
+        v = v * sc + sh;
+        if (p.relu) v = fmaxf(v, 0.f);
+        p.y[rw * p.ldy + col] = v;
+    }
+}
+
 // y[g,c] = max over the blocks_per_group partial rows of group g
 __global__ void pool_finish_kernel(long groups, int cout, int blocks_per_group,
                                    const float *__restrict__ partial, float *__restrict__ y, int ldy)
@@ -377,6 +558,14 @@ template <int MODE>
 int launch_mlp(const MlpParams &p, hipStream_t st, unsigned samples = 1)
 {
     const long rb = (p.rows + kBM - 1) / kBM;
+    const long fr_blocks = ((p.rows + kFrRows - 1) / kFrRows) * ((p.cout + kFrCols - 1) / kFrCols);
+    if constexpr (MODE != kFlipoutFold) {
+        if (p.pool_rows == 0 && fr_blocks <= 1024 && p.cin >= 32) {
+            // few rows: 32 x 64 tiles, K split over the workgroup's waves
+            hipLaunchKernelGGL((fewrow_mlp_kernel<MODE>), dim3((unsigned)fr_blocks, samples), dim3(kMlpThreads), 0, st, p);
+            return check_launch("fpn_shared_mlp(few rows)");
+        }
+    }
     if (p.pool_rows == 0 && p.cout > 64 && rb * ((p.cout + 127) / 128) < 256) {
         // few rows (the fully connected layers: one row per frustum): 128-row tiles
         // would leave most of the chip idle, so use 32-row x 128-column tiles

@@ -11,8 +11,12 @@ from . import _lib
 launch_observer = None
 
 
-def mlp_kernel_name(cout):
-    """Which tile configuration fpn_shared_mlp_f32 launches for a layer width."""
+def mlp_kernel_name(cout, rows=None, cin=None, pool_rows=0):
+    """Which configuration fpn_shared_mlp_f32 launches: the split-K kernel for few rows
+    (at most 1024 tiles of 32 x 64, no fused pooling), else 128-row tiles by layer width."""
+    if rows is not None and cin is not None and not pool_rows and cin >= 32 and \
+            -(-rows // 32) * -(-cout // 64) <= 1024:
+        return "shared_mlp_fewrow"
     return "shared_mlp_128x128" if cout > 64 else ("shared_mlp_128x64" if cout > 32 else "shared_mlp_128x32")
 
 
@@ -72,7 +76,7 @@ def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=
     if ws_bytes:
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     obs = launch_observer
-    tok = obs.begin(mlp_kernel_name(cout), rows, cin, cout) if obs is not None else None
+    tok = obs.begin(mlp_kernel_name(cout, rows, cin, pool_rows), rows, cin, cout) if obs is not None else None
     with torch.cuda.device(x.device):
         _lib.check(lib.fpn_shared_mlp_f32(rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(w), _lib.ptr(scale),
                                           _lib.ptr(shift), _lib.ptr(group_bias), int(rows_per_group),
