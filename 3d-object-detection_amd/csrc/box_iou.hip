@@ -114,6 +114,22 @@ __global__ void box_iou_pairs_kernel(long n, const double *__restrict__ a, long 
     if (i < n) iou[i] = box_iou(a + i * stride_a, b + i * stride_b);
 }
 
+// the two factors of the intersection volume, separately: area of the overlap of the
+// ground rectangles (:162-167) and overlap of the height intervals (:156-160)
+__global__ void box_intersection_kernel(long n, const double *__restrict__ a, long stride_a,
+                                        const double *__restrict__ b, long stride_b, double *__restrict__ area,
+                                        double *__restrict__ height)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ground ga, gb;
+    ground_of(a + i * stride_a, ga);
+    ground_of(b + i * stride_b, gb);
+    const double dz = fmin(gb.max_z, ga.max_z) - fmax(gb.min_z, ga.min_z);
+    if (height) height[i] = dz > 0 ? dz : 0.0;
+    if (area) area[i] = quad_intersection_area(ga, gb);
+}
+
 __global__ void box_best_overlap_kernel(int npred, const double *__restrict__ pred, const double *__restrict__ gt,
                                         const int *__restrict__ gt_begin, const int *__restrict__ gt_count,
                                         double *__restrict__ best_iou, int *__restrict__ best_j)
@@ -153,6 +169,19 @@ int fpn_box3d_iou_f64(long n, const double *a, long stride_a, const double *b, l
     hipLaunchKernelGGL(box_iou_pairs_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, as_stream(stream), n, a,
                        stride_a, b, stride_b, iou);
     return check_launch("fpn_box3d_iou_f64");
+}
+
+int fpn_box3d_intersection_f64(long n, const double *a, long stride_a, const double *b, long stride_b,
+                               double *area, double *height, void *stream)
+{
+    FPN_REQUIRE(n >= 0, "box3d_intersection: negative count %ld", n);
+    if (n == 0) return FPN_OK;
+    FPN_REQUIRE(a && b && (area || height), "box3d_intersection: null pointer");
+    FPN_REQUIRE((stride_a == 0 || stride_a >= 10) && (stride_b == 0 || stride_b >= 10),
+                "box3d_intersection: box strides must be 0 (broadcast) or >= 10 doubles (got %ld, %ld)", stride_a, stride_b);
+    hipLaunchKernelGGL(box_intersection_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, as_stream(stream), n, a,
+                       stride_a, b, stride_b, area, height);
+    return check_launch("fpn_box3d_intersection_f64");
 }
 
 int fpn_box3d_best_overlap_f64(int npred, const double *pred, const double *gt, const int *gt_begin,

@@ -677,7 +677,7 @@ constexpr int kMgThreads = 256;
 constexpr int kMgMaxN = 16384;
 
 __global__ __launch_bounds__(kMgThreads) void mask_gather_kernel(
-    int n, int cpc, int npick, const float *__restrict__ pc, const float *__restrict__ logits,
+    int n, int cpc, int npick, int spread, const float *__restrict__ pc, const float *__restrict__ logits,
     float *__restrict__ mask, float *__restrict__ mean, int *__restrict__ sel,
     float *__restrict__ obj)
 {
@@ -762,8 +762,11 @@ __global__ __launch_bounds__(kMgThreads) void mask_gather_kernel(
     __syncthreads();
     const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
     for (int t = tid; t < npick; t += kMgThreads) {
+        // more positives than slots: the first npick of them, or (spread) every
+        // total/npick-th one, which covers the whole object whatever the point order;
+        // fewer: all of them, repeated cyclically
         int k = 0;
-        if (total > 0) k = s_pos[total >= npick ? t : t % total];
+        if (total > 0) k = s_pos[total >= npick ? (spread ? (int)((long)t * total / npick) : t) : t % total];
         if (sel) sel[(size_t)bi * npick + t] = k;
         float *dst = obj + ((size_t)bi * npick + t) * 3;
         dst[0] = p[(size_t)k * cpc + 0] - mx;
@@ -957,15 +960,16 @@ int fpn_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, f
     return check_launch("fpn_select_top_k");
 }
 
-int fpn_mask_gather(int b, int n, int cpc, int npick, const float *point_cloud, const float *logits,
+int fpn_mask_gather(int b, int n, int cpc, int npick, int policy, const float *point_cloud, const float *logits,
                     float *mask, float *mean, int *sel, float *obj, void *stream)
 {
     FPN_REQUIRE(b >= 0 && n >= 1 && cpc >= 3 && npick >= 1, "mask_gather: bad size (n=%d cpc=%d npick=%d)", n, cpc, npick);
+    FPN_REQUIRE(policy == FPN_PICK_FIRST || policy == FPN_PICK_SPREAD, "mask_gather: unknown pick policy %d", policy);
     if (b == 0) return FPN_OK;
     FPN_REQUIRE(point_cloud && logits && mean && obj, "mask_gather: null pointer");
     if (n > kMgMaxN) return fail(FPN_E_UNSUPPORTED, "mask_gather: n=%d exceeds %d", n, kMgMaxN);
     hipLaunchKernelGGL(mask_gather_kernel, dim3(b), dim3(kMgThreads), (size_t)n * 4, as_stream(stream), n,
-                       cpc, npick, point_cloud, logits, mask, mean, sel, obj);
+                       cpc, npick, policy == FPN_PICK_SPREAD ? 1 : 0, point_cloud, logits, mask, mean, sel, obj);
     return check_launch("fpn_mask_gather");
 }
 

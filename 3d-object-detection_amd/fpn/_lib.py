@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class FpnError(RuntimeError):
@@ -67,8 +67,9 @@ SIGNATURES = {
     "fpn_fp_head_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_box3d_iou_f64": [_l, _vp, _l, _vp, _l, _vp, _vp],
+    "fpn_box3d_intersection_f64": [_l, _vp, _l, _vp, _l, _vp, _vp, _vp],
     "fpn_box3d_best_overlap_f64": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "fpn_mask_gather": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fpn_mask_gather": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

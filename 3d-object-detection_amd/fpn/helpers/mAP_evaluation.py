@@ -53,6 +53,20 @@ def _iou_pairs(a, b, device=None):
     return out.cpu().numpy()
 
 
+def _intersection_pair(a, b, device=None):
+    """(ground-rectangle overlap area, height overlap) of two packed boxes, float64, through
+    fpn_box3d_intersection_f64."""
+    dev = _device(device)
+    ta = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).reshape(1, _FIELDS)).to(dev)
+    tb = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64).reshape(1, _FIELDS)).to(dev)
+    out = torch.empty(2, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().fpn_box3d_intersection_f64(1, _lib.ptr(ta), _FIELDS, _lib.ptr(tb), _FIELDS,
+                                                          _lib.ptr(out[0:1]), _lib.ptr(out[1:2]), _lib.stream_of(out)))
+    area, height = out.cpu().tolist()
+    return area, height
+
+
 class Box3D:
     """A prediction or a ground-truth box (mAP_evaluation.py:50-202).  Keeps the
     reference's attributes; `ground_bbox_coords` is the (4,2) corner array of the
@@ -124,15 +138,17 @@ class Box3D:
     def get_height_intersection(self, other):
         return max(0, min(other.max_z, self.max_z) - max(other.min_z, self.min_z))
 
-    def get_intersection(self, other):
-        """Volume of the intersection (:169-174), recovered from the IoU and the two
-        volumes: I = iou (Va + Vb) / (1 + iou)."""
-        iou = float(self.get_iou(other))
-        return iou * (self.volume + other.volume) / (1.0 + iou)
+    def get_area_intersection(self, other, device=None):
+        """Area of the overlap of the two ground rectangles (:162-167), with the
+        reference's sanity assertion."""
+        result, _ = _intersection_pair(self.packed(), other.packed(), device)
+        assert result <= self.width * self.length
+        return result
 
-    def get_area_intersection(self, other):
-        h = self.get_height_intersection(other)
-        return self.get_intersection(other) / h if h > 0 else 0.0
+    def get_intersection(self, other, device=None):
+        """Volume of the intersection: height overlap x ground overlap (:169-174)."""
+        area, _ = _intersection_pair(self.packed(), other.packed(), device)
+        return self.get_height_intersection(other) * area
 
     def get_iou(self, other, device=None):
         return _iou_pairs(self.packed(), other.packed(), device)[0]

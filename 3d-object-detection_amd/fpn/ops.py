@@ -340,10 +340,23 @@ def v1_obj_chain_bf16(obj2d, m, box, delta, wstream, consts, feat_max, copy_vecs
         obs.end(tok)
 
 
-def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True, mask=None, mean=None, sel=None):
+# How the npick object points are chosen when a frustum has MORE positives than that (the
+# reference draws a random subset, models/model_util.py:73-75): "first" = the first npick in
+# index order, "spread" = evenly spaced over the positives (unbiased for inputs whose point
+# order is not random).  Module default used by the models; per call through `policy`.
+OBJECT_POINT_POLICY = "first"
+_PICK = {"first": 0, "spread": 1}
+
+
+def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True, mask=None, mean=None, sel=None,
+                policy=None):
     """point_cloud (B,N,C>=3), logits (B,N,2) -> mask (B,N), mean (B,3), sel
     (B,npick) int32, obj (B,npick,3) through fpn_mask_gather.  mask / mean / sel: dense
-    tensors of those shapes to write into (allocated when None)."""
+    tensors of those shapes to write into (allocated when None).  policy: "first" |
+    "spread" (default: OBJECT_POINT_POLICY)."""
+    policy = OBJECT_POINT_POLICY if policy is None else policy
+    if policy not in _PICK:
+        raise ValueError("object-point policy must be 'first' or 'spread', got %r" % (policy,))
     _lib.require_device_tensor("point_cloud", point_cloud, torch.float32, 3)
     _lib.require_device_tensor("logits", logits, torch.float32, 3, 2)
     b, n, c = point_cloud.shape
@@ -362,7 +375,7 @@ def mask_gather(point_cloud, logits, npick, want_mask=True, want_sel=True, mask=
         sel = torch.empty((b, npick), dtype=torch.int32, device=dev)
     obj = torch.empty((b, npick, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().fpn_mask_gather(b, n, c, int(npick), _lib.ptr(point_cloud), _lib.ptr(logits),
+        _lib.check(_lib.load().fpn_mask_gather(b, n, c, int(npick), _PICK[policy], _lib.ptr(point_cloud), _lib.ptr(logits),
                                                _lib.ptr(mask), _lib.ptr(mean), _lib.ptr(sel), _lib.ptr(obj),
                                                _lib.stream_of(point_cloud)))
     return mask, mean, sel, obj

@@ -461,19 +461,25 @@ int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const flo
  * (the reference leaves the graph for numpy through tf.py_func, :84):
  *   mask[i,j]      = logits[i,j,0] < logits[i,j,1]            (as 0/1 f32)
  *   mean[i,:]      = sum_j mask*xyz / max(count,1)
- *   sel[i,0:npick] = indices of the object points: the first npick positives in
- *                    index order when count >= npick, otherwise the positives
- *                    repeated cyclically; all zero when count == 0.  (The
- *                    reference draws this set with numpy's global RNG; for
- *                    count <= npick the SET is the same, and the nets after it
- *                    are invariant to order and repetition.)
+ *   sel[i,0:npick] = indices of the object points.  count <= npick: the positives in
+ *                    index order, repeated cyclically; all zero when count == 0.  (The
+ *                    reference draws this set with numpy's global RNG; for count <=
+ *                    npick the SET is the same, and the nets after it are invariant to
+ *                    order and repetition.)  count > npick, where the reference draws a
+ *                    random subset: policy FPN_PICK_FIRST takes the first npick
+ *                    positives in index order, FPN_PICK_SPREAD positive number
+ *                    floor(t * count / npick) for slot t - evenly spaced over the list,
+ *                    so the subset covers the whole object whatever order the points
+ *                    arrive in (raw sensor order is not random).
  *   obj[i,t,:]     = xyz[i,sel[i,t],:] - mean[i,:]
  *   point_cloud (b,n,cpc) with xyz in channels 0..2; logits (b,n,2).
  *   Outputs: mask (b,n) f32, mean (b,3), sel (b,npick) i32, obj (b,npick,3);
  *   mask and sel may be NULL.  Limits: n <= 16384, npick <= n or any npick when
  *   positives repeat.
  */
-int fpn_mask_gather(int b, int n, int cpc, int npick, const float *point_cloud,
+#define FPN_PICK_FIRST 0
+#define FPN_PICK_SPREAD 1
+int fpn_mask_gather(int b, int n, int cpc, int npick, int policy, const float *point_cloud,
                     const float *logits, float *mask, float *mean, int *sel, float *obj,
                     void *stream);
 
@@ -492,6 +498,16 @@ int fpn_mask_gather(int b, int n, int cpc, int npick, const float *point_cloud,
  */
 int fpn_box3d_iou_f64(long n, const double *a, long stride_a, const double *b, long stride_b,
                       double *iou, void *stream);
+
+/*
+ * The two factors of a box pair's intersection volume, for callers of the evaluation's
+ * Box3D.get_area_intersection (helpers/mAP_evaluation.py:162-167: area of the overlap of
+ * the two ground rectangles) and get_height_intersection / get_intersection (:156-160,
+ * :169-174: overlap of the height intervals; their product is the volume).  Boxes, strides
+ * and arithmetic as fpn_box3d_iou_f64; area (n) and height (n), either may be NULL.
+ */
+int fpn_box3d_intersection_f64(long n, const double *a, long stride_a, const double *b, long stride_b,
+                               double *area, double *height, void *stream);
 
 /*
  * The inner search of recall_precision (helpers/mAP_evaluation.py:282-297) for all

@@ -92,7 +92,9 @@ def select_object_points(mask, npoints=NUM_OBJECT_POINT, policy="first", rng=Non
       count <= npoints the selected SET equals the reference's for every RNG
       state, and everything downstream is a per-point MLP followed by a max over
       points, so the result does not depend on order or repetition.
-    An empty mask gives all-zero indices in both (:67,71)."""
+    policy 'spread' (the build's other option for count > npoints): positive number
+      floor(t * count / npoints) for slot t, evenly spaced over the positives.
+    An empty mask gives all-zero indices in all of them (:67,71)."""
     B, _ = mask.shape
     idx = np.zeros((B, npoints), np.int32)
     for i in range(B):
@@ -106,8 +108,12 @@ def select_object_points(mask, npoints=NUM_OBJECT_POINT, policy="first", rng=Non
                 choice = rng.choice(len(pos), npoints - len(pos), replace=True)
                 choice = np.concatenate((np.arange(len(pos)), choice))
             rng.shuffle(choice)
+        elif len(pos) <= npoints:
+            choice = np.arange(npoints) % len(pos)
+        elif policy == "spread":
+            choice = (np.arange(npoints, dtype=np.int64) * len(pos)) // npoints
         else:
-            choice = np.arange(npoints) % len(pos) if len(pos) <= npoints else np.arange(npoints)
+            choice = np.arange(npoints)
         idx[i] = pos[choice]
     return idx
 

@@ -97,8 +97,15 @@ def test_box3d_interface(device):
     np.testing.assert_array_equal(a.ground_bbox_coords, [(2, -1), (2, 1), (-2, 1), (-2, -1)])
     assert a.get_iou(b) == 0.6 and b.get_iou(a) == 0.6
     assert a.get_height_intersection(b) == 2
-    assert a.get_intersection(b) == pytest.approx(12.0, abs=1e-12)
-    assert a.get_area_intersection(b) == pytest.approx(6.0, abs=1e-12)
+    assert a.get_intersection(b) == 12.0 and a.get_area_intersection(b) == 6.0      # computed, not derived from the IoU
+    # rotated pair, disjoint in height: zero volume but the ground rectangles still overlap;
+    # against the numpy restatement of the evaluation
+    from oracle import map_numpy as om
+    q = [np.cos(0.35), 0, 0, np.sin(0.35)]
+    c = me.Box3D(sample_token="s", translation=[0.5, 0.25, 10], size=[1.5, 3, 2], rotation=q, name="car")
+    assert a.get_height_intersection(c) == 0 and a.get_intersection(c) == 0 and a.get_iou(c) == 0
+    want = om.quad_intersection_area(om.ground_corners(om.pack(a.serialize())), om.ground_corners(om.pack(c.serialize())))
+    assert want > 0 and a.get_area_intersection(c) == want
     assert me.get_ious([a, b], b) == [0.6, 1.0]
     assert me.get_ious([], b) == []
     with pytest.raises(AssertionError):

@@ -213,6 +213,20 @@ def test_mask_gather(device):
         np.testing.assert_array_equal(sel.cpu().numpy(), widx)
         np.testing.assert_allclose(mean.cpu().numpy(), wmean, rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(obj.cpu().numpy(), wobj, rtol=1e-5, atol=1e-4)
+        # the evenly spaced pick: same mask and centroid, another subset when count > 512
+        mask2, mean2, sel2, obj2 = ops.mask_gather(dev(pc, device), dev(logits, device), 512, policy="spread")
+        wobj, wmean, wmask, widx = V.point_cloud_masking(pc, logits, policy="spread")
+        assert torch.equal(mask2, mask) and torch.equal(mean2, mean)
+        np.testing.assert_array_equal(sel2.cpu().numpy(), widx)
+        np.testing.assert_allclose(obj2.cpu().numpy(), wobj, rtol=1e-5, atol=1e-4)
+        many = wmask.sum(1) > 512
+        assert np.array_equal(sel2.cpu().numpy()[~many], sel.cpu().numpy()[~many])
+        if many.any():
+            s2 = sel2.cpu().numpy()[many]
+            assert (np.diff(s2, axis=1) > 0).all() and not np.array_equal(s2, sel.cpu().numpy()[many])
+            assert (s2[:, -1] > sel.cpu().numpy()[many][:, -1]).all()       # reaches beyond the first 512 positives
+    with pytest.raises(ValueError):
+        ops.mask_gather(dev(pc, device), dev(logits, device), 512, policy="random")
 
 
 def test_argument_errors(device):
