@@ -286,9 +286,13 @@ __device__ __forceinline__ BlockXY frustum_major_block()
 // ---------------------------------------------------------------------------
 constexpr int kQbThreads = 256;
 constexpr int kQbTile = 4096;  // dataset points per LDS tile (48 KiB)
+#ifndef FPN_QB_TARGET
+#define FPN_QB_TARGET 4096
+#endif
+constexpr int kQbTargetBlocks = FPN_QB_TARGET;   // workgroups a launch aims for (queries per workgroup follow)
 
 __global__ __launch_bounds__(kQbThreads) void query_ball_kernel(
-    int n, int m, float smax, int nsample, int qpb, const float *__restrict__ xyz1,
+    int n, int m, float smax, int nsample, int qpb, int tile_pts, const float *__restrict__ xyz1,
     const float *__restrict__ xyz2, int *__restrict__ idx, int *__restrict__ pts_cnt)
 {
     extern __shared__ float smem[];
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(kQbThreads) void query_ball_kernel(
     const float *query = xyz2 + (size_t)bi * m * 3;
     const int q0 = blk.x * qpb, q1 = min(m, q0 + qpb);
 
-    float *tile = smem;                                       // kQbTile*3 floats
-    int *s_cnt = reinterpret_cast<int *>(smem + kQbTile * 3); // qpb
+    float *tile = smem;                                       // tile_pts*3 floats (tile_pts = min(n, kQbTile))
+    int *s_cnt = reinterpret_cast<int *>(smem + tile_pts * 3); // qpb
     int *s_first = s_cnt + qpb;                               // qpb
 
     for (int q = q0 + tid; q < q1; q += kQbThreads) {
@@ -309,8 +313,8 @@ __global__ __launch_bounds__(kQbThreads) void query_ball_kernel(
         s_first[q - q0] = 0;
     }
 
-    for (int t0 = 0; t0 < n; t0 += kQbTile) {
-        const int tn = min(kQbTile, n - t0);
+    for (int t0 = 0; t0 < n; t0 += tile_pts) {
+        const int tn = min(tile_pts, n - t0);
         __syncthreads();  // previous tile fully consumed (and state initialised)
         for (int i = tid; i < tn * 3; i += kQbThreads) tile[i] = data[(size_t)t0 * 3 + i];
         __syncthreads();
@@ -854,13 +858,16 @@ int fpn_query_ball_point(int b, int n, int m, float radius, int nsample, const f
     FPN_REQUIRE(b <= 65535, "query_ball_point: batch %d exceeds 65535", b);
     // queries per workgroup: enough workgroups to cover the chip several times
     // over, but not so few queries that the tile staging dominates
-    long want = ((long)b * m + 2047) / 2048;
+    long want = ((long)b * m + kQbTargetBlocks - 1) / kQbTargetBlocks;
     int qpb = (int)std::min<long>(std::max<long>(want, 4), 64);
     qpb = (qpb + 3) & ~3;
-    size_t lds = (size_t)kQbTile * 3 * 4 + (size_t)qpb * 2 * 4;
+    // LDS for the points actually staged (a 2048-point frustum takes 24 KiB, not the 48 KiB of
+    // a full tile): twice the workgroups per CU to cover each other's staging and stores
+    const int tile_pts = std::max(1, std::min(n, kQbTile));
+    size_t lds = (size_t)tile_pts * 3 * 4 + (size_t)qpb * 2 * 4;
     dim3 grid((m + qpb - 1) / qpb, b);
     hipLaunchKernelGGL(query_ball_kernel, grid, dim3(kQbThreads), lds, as_stream(stream), n, m,
-                       ball_threshold(radius), nsample, qpb, xyz1, xyz2, idx, pts_cnt);
+                       ball_threshold(radius), nsample, qpb, tile_pts, xyz1, xyz2, idx, pts_cnt);
     return check_launch("fpn_query_ball_point");
 }
 
