@@ -1,5 +1,6 @@
-"""Times fpn_fc_stack_f32 against one fpn_shared_mlp_f32 call per layer on the three
-fully connected stacks of the v1 network (HIP events, 50 launches each)."""
+"""The three fully connected stacks of the v1 network, one fpn_shared_mlp_f32 call per layer
+(HIP events over 50 repetitions; run under tools/fc_trace.sh for GPU-side durations per
+launch: events around single small launches measure the host's launch rate)."""
 import os
 import sys
 
@@ -31,8 +32,6 @@ def main():
             layers.append((torch.randn((cin, cout), device=dev) * cin ** -0.5, torch.rand(cout, device=dev) + 0.5,
                            torch.randn(cout, device=dev) * 0.1, True))
         x = torch.randn((rows, widths[0]), device=dev)
-        stack = ops.FcStack(layers)
-        out = torch.empty((rows, widths[-1]), device=dev)
 
         def per_layer():
             a = x
@@ -40,8 +39,8 @@ def main():
                 a = ops.shared_mlp(a, w, s, h, relu=r)
             return a
         macs = rows * sum(a * b for a, b in zip(widths[:-1], widths[1:]))
-        t_stack, t_layers = timed(lambda: stack(x, out=out)), timed(per_layer)
-        print("%-20s rows %5d: stack %7.1f us (%5.1f TFLOP/s)   per layer %7.1f us" % (name, rows, t_stack, 2 * macs / t_stack / 1e6, t_layers))
+        t_layers = timed(per_layer)
+        print("%-20s rows %5d: %7.1f us for %d launches (%5.1f TFLOP/s)" % (name, rows, t_layers, len(layers), 2 * macs / t_layers / 1e6))
 
 
 if __name__ == "__main__":
