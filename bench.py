@@ -413,9 +413,8 @@ def build_v2(args, dev, rank, world):
     pc_np, oh_np = synthetic.make_frustums_range(lo, hi, points, 4, seed=0)
     pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
     st = variables.VariableStore(dev, seed=1)
-    if args.dtype == "bf16":
-        from fpn import pointnet_util
-        pointnet_util.SA_PRECISION = "bf16"       # the fused set-abstraction kernels
+    from fpn import pointnet_util
+    pointnet_util.SA_PRECISION = "bf16" if args.dtype == "bf16" else "fp32"      # the fused set-abstraction kernels
     with variables.use_store(st):
         M2.get_model(pc[:2], one_hot[:2], False)      # creates the variables
     st.randomize_batch_norm(2)
@@ -481,48 +480,10 @@ def build_bayes(args, dev, rank, world):
 
 # ---- main ---------------------------------------------------------------------------------
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None,
-                    help="frustums per GPU (default: 1024 for v1, 256 for v2, 128 for bayes)")
-    ap.add_argument("--points", type=int, default=None, help="points per frustum (default: 1024; 2048 for v2)")
-    ap.add_argument("--chunk", type=int, default=0, help="frustums per chunk (0 = plan default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--no-pointset", action="store_true", help="skip the point-set operator bandwidth table")
-    ap.add_argument("--config", choices=("v1", "v2", "bayes"), default="v1",
-                    help="v1: BASELINE config 1 (the headline metric, default); v2: PointNet++ variant, 2048 points "
-                         "(config 2); bayes: Flipout v1 with --samples Monte-Carlo passes per frustum (config 3)")
-    ap.add_argument("--stream-total", type=int, default=0,
-                    help="--config v2: frustums per GPU held in host memory and streamed through the model in "
-                         "chunks of --batch (BASELINE config 5's access pattern); a step = the whole set")
-    ap.add_argument("--samples", type=int, default=32, help="Monte-Carlo samples per frustum (--config bayes)")
-    ap.add_argument("--mc-dropout", action=argparse.BooleanOptionalAction, default=True,
-                    help="--config bayes: keep the Dropout(0.5) before the segmentation head active (Monte-Carlo "
-                         "dropout, as BASELINE's Bayesian configuration samples; --no-mc-dropout: Flipout noise only)")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="operand type of the layer-chain kernels' matrix products (accumulation is always fp32); "
-                         "f32 is the headline configuration")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a HIP graph (--config v2; removes the host launch overhead)")
-    args = ap.parse_args()
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be at least 1")
-    if args.stream_total and args.config != "v2":
-        raise SystemExit("--stream-total goes with --config v2")
-
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus))         # this process never touches a GPU
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    dev = init_rank(local_rank, world)
-
+def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
+    """Warm-up, timed region and the report of one workload (args.config, args.dtype, ...);
+    returns the JSON object (complete on rank 0).  extras: also the point-set operator
+    tables and the CPU baseline."""
     from fpn import dist as fdist
     from fpn import ops
     wl = {"v1": build_v1, "v2": build_v2, "bayes": build_bayes}[args.config](args, dev, rank, world)
@@ -619,16 +580,80 @@ def main():
             out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
                                   "tflops": v[1] / v[2] / 1e12 if v[2] > 0 else None} for k, v in full.items()}
             out["kernels_source"] = "3 steps after the timed region, HIP events around every fused launch"
-        if world == 1 and not args.no_pointset and args.config in ("v1", "v2"):
+        if extras and world == 1 and not args.no_pointset and args.config in ("v1", "v2"):
             # 256 frustums = one workgroup per CU for the per-frustum kernels (FPS, ball
             # query): latency-bound; 4096 frustums lets several workgroups share a CU
             out["pointset_ops"] = pointset_ops(dev)
             out["pointset_ops_4096_frustums"] = pointset_ops(dev, frustums=4096, reps=5)
             if not args.no_cpu_baseline:
                 out["pointset_cpu"] = pointset_cpu()
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl["cpu"], samples=args.samples,
+        if extras and not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl["cpu"], seconds=cpu_seconds, samples=args.samples,
                                                params=wl["params"]() if "params" in wl else None)
+    return out
+
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frustums per GPU (default: 1024 for v1, 256 for v2, 128 for bayes)")
+    ap.add_argument("--points", type=int, default=None, help="points per frustum (default: 1024; 2048 for v2)")
+    ap.add_argument("--chunk", type=int, default=0, help="frustums per chunk (0 = plan default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-pointset", action="store_true", help="skip the point-set operator bandwidth table")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="default run only: skip the v2 and Bayes workloads reported under `side_workloads`")
+    ap.add_argument("--config", choices=("v1", "v2", "bayes"), default="v1",
+                    help="v1: BASELINE config 1 (the headline metric, default); v2: PointNet++ variant, 2048 points "
+                         "(config 2); bayes: Flipout v1 with --samples Monte-Carlo passes per frustum (config 3)")
+    ap.add_argument("--stream-total", type=int, default=0,
+                    help="--config v2: frustums per GPU held in host memory and streamed through the model in "
+                         "chunks of --batch (BASELINE config 5's access pattern); a step = the whole set")
+    ap.add_argument("--samples", type=int, default=32, help="Monte-Carlo samples per frustum (--config bayes)")
+    ap.add_argument("--mc-dropout", action=argparse.BooleanOptionalAction, default=True,
+                    help="--config bayes: keep the Dropout(0.5) before the segmentation head active (Monte-Carlo "
+                         "dropout, as BASELINE's Bayesian configuration samples; --no-mc-dropout: Flipout noise only)")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="operand type of the layer-chain kernels' matrix products (accumulation is always fp32); "
+                         "f32 is the headline configuration")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a HIP graph (--config v2; removes the host launch overhead)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.stream_total and args.config != "v2":
+        raise SystemExit("--stream-total goes with --config v2")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))         # this process never touches a GPU
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = init_rank(local_rank, world)
+
+    out = measure(args, dev, rank, world)
+    if rank == 0:
+        if world == 1 and args.config == "v1" and args.dtype == "f32" and not args.no_side_workloads \
+                and not (args.batch or args.points or args.chunk):
+            # the other GPU configurations BASELINE names, measured in this same run with the
+            # same protocol (fewer steps): each is a complete report of its own under its key
+            import copy
+            out["side_workloads"] = {}
+            for key, config, dtype, steps in (("v2_f32", "v2", "f32", 10), ("v2_bf16", "v2", "bf16", 10),
+                                              ("bayes_f32", "bayes", "f32", 3), ("bayes_bf16", "bayes", "bf16", 3)):
+                side = copy.copy(args)
+                side.config, side.dtype, side.steps, side.warmup = config, dtype, steps, 2
+                side.no_pointset = True
+                # (one CPU baseline per graph: the bf16 variants run the same graph as the f32 ones)
+                out["side_workloads"][key] = measure(side, dev, rank, world, extras=dtype == "f32", cpu_seconds=4.0)
+                torch.cuda.empty_cache()
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
