@@ -996,7 +996,8 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
     FPN_REQUIRE(ns % 32 == 0, "sa_chain_bf16: samples per ball (%d) must be a multiple of 32", ns);
     FPN_REQUIRE(c3_valid >= 64 && c3_valid % 64 == 0 && c3_valid <= c3 && ldo >= c3_valid,
                 "sa_chain_bf16: bad output width %d (c3 %d, ld %d)", c3_valid, c3, ldo);
-    if (!fpn_sa_chain_supported(cf, c1, c2, c3))
+    // (the bf16 weight streams pair output tiles: every width a multiple of 64)
+    if (c2 % 64 != 0 || !fpn_sa_chain_supported(cf, c1, c2, c3))
         return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
     if (b == 0) return FPN_OK;
     FPN_REQUIRE(xyz && new_xyz && idx && wstream && consts && out && (cf == 0 || feat), "sa_chain_bf16: null pointer");

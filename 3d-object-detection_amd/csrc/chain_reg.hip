@@ -149,6 +149,16 @@ __device__ __forceinline__ void mfma_pair(floatx16 &acc_a, floatx16 &acc_b, cons
     }
 }
 
+// One output tile against one activation tile (the odd last tile of a layer whose width is
+// an odd number of 32-channel tiles): 16 MFMA steps on one accumulator.  Back-to-back
+// dependent MFMAs of this shape issue at the pipe's rate (their latency equals their issue
+// time), so the single chain costs nothing extra per MFMA.
+__device__ __forceinline__ void mfma_single(floatx16 &acc, const WChunk &w, const floatx16 &act)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(w.q[r >> 2], r & 3), act[r], acc, 0, 0, 0);
+}
+
 // Flipout: each frustum has its own effective weights (fpn_flipout_weights_f32), so
 // the weight stream of a wave is its frustum's copy.  The workgroups of one frustum are
 // then placed on ONE XCD (consecutive workgroup ids go round the eight XCDs, so id i
@@ -397,13 +407,17 @@ __device__ __forceinline__ void layer_t(floatx16 (&out)[NT], const floatx16 (&in
                                         const float *__restrict__ sc, const float *__restrict__ sh, WChunk (&ring)[4],
                                         const float4 *next0, const float4 *next1, unsigned lane, int h)
 {
-    static_assert(NJ >= 2 && NT % 2 == 0, "unsupported layer shape");
-    constexpr int kSteps = (NT / 2) * NJ;
+    // NT odd: the last "pair" is a single tile - its steps are 16 MFMAs on one accumulator
+    // and request one weight chunk instead of two
+    static_assert(NJ >= 2 && NT >= 2, "unsupported layer shape");
+    constexpr int NP = (NT + 1) / 2;             // output tile pairs (the last one may be half)
+    constexpr int kSteps = NP * NJ;
     TileConst csc[2], csh[2];
     static_for<0, kSteps>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ;
         constexpr int cur = 2 * ((S + P0) & 1), nxt = 2 * ((S + P0 + 1) & 1);
         constexpr bool ride_load = tp > 0 && j == 0, ride = tp > 0 && j == 1;
+        constexpr bool pair = 2 * tp + 1 < NT;
         if constexpr (ride_load) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -414,7 +428,7 @@ __device__ __forceinline__ void layer_t(floatx16 (&out)[NT], const floatx16 (&in
         if constexpr (S + 1 < kSteps) {
             constexpr int tp1 = (S + 1) / NJ, j1 = (S + 1) % NJ;
             load_chunk(ring[nxt], w + (size_t)((2 * tp1) * NJ + j1) * 256, lane);
-            load_chunk(ring[nxt + 1], w + (size_t)((2 * tp1 + 1) * NJ + j1) * 256, lane);
+            if constexpr (2 * tp1 + 1 < NT) load_chunk(ring[nxt + 1], w + (size_t)((2 * tp1 + 1) * NJ + j1) * 256, lane);
         } else {
             load_chunk(ring[nxt], next0, lane);
             load_chunk(ring[nxt + 1], next1, lane);
@@ -425,18 +439,24 @@ __device__ __forceinline__ void layer_t(floatx16 (&out)[NT], const floatx16 (&in
         }
         if constexpr (j == 0) {
             zero(out[2 * tp]);
-            zero(out[2 * tp + 1]);
+            if constexpr (pair) zero(out[2 * tp + 1]);
         }
-        mfma_pair(out[2 * tp], out[2 * tp + 1], ring[cur], ring[cur + 1], in[j]);
-        sched_step<32, ride_load ? 24 : 8, ride ? 4 : 0, 8>();
+        if constexpr (pair) {
+            mfma_pair(out[2 * tp], out[2 * tp + 1], ring[cur], ring[cur + 1], in[j]);
+            sched_step<32, ride_load ? 24 : 8, ride ? 4 : 0, 8>();
+        } else {
+            mfma_single(out[2 * tp], ring[cur], in[j]);
+            sched_step<16, ride_load ? 16 : 8, ride ? 8 : 0, 4>();
+        }
     });
+    constexpr int kLast = 2 * (NP - 1);          // first tile of the last pair
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        load_const(csc[u], sc, 32 * (NT - 2 + u) + 4 * h);
-        load_const(csh[u], sh, 32 * (NT - 2 + u) + 4 * h);
+    for (int u = 0; u < NT - kLast; ++u) {
+        load_const(csc[u], sc, 32 * (kLast + u) + 4 * h);
+        load_const(csh[u], sh, 32 * (kLast + u) + 4 * h);
     }
-    bn_relu(out[NT - 2], csc[0], csh[0]);
-    bn_relu(out[NT - 1], csc[1], csh[1]);
+    bn_relu(out[kLast], csc[0], csh[0]);
+    if constexpr (kLast + 1 < NT) bn_relu(out[kLast + 1], csc[1], csh[1]);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -526,7 +546,7 @@ __device__ __forceinline__ void layer_max(const floatx16 (&in)[NJ], const float4
                                           int *gmax, WChunk (&ring)[4], unsigned lane, int h,
                                           int cvalid = 32 * NT)
 {
-    static_assert(NJ >= 2 && NJ % 2 == 0 && NT % 4 == 0, "unsupported layer shape");
+    static_assert(NJ >= 2 && NT % 4 == 0, "unsupported layer shape");
     const int c = lane & 31;
     floatx16 acc[2][2];
     zero(acc[1][0]);
@@ -1075,7 +1095,8 @@ int fpn_sa_chain_supported(int cf, int c1, int c2, int c3)
 {
     const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32, t3 = c3 / 32;
     if (cf >= 32 ? cf % 32 != 0 : cf > 5) return 0;
-    if (c1 % 64 || c2 % 64 || c3 % 128) return 0;
+    if (c1 % 64 || c2 % 32 || c3 % 128) return 0;
+    if (c2 % 64) return njf == 0 && t1 == 2 && t2 == 3 && t3 == 4;      // a 96-wide middle layer, unpadded
     return (njf == 0 && t1 == 2 && t2 == 2 && t3 == 4) || (njf == 0 && t1 == 2 && t2 == 4 && t3 == 4) ||
            (njf == 10 && t1 == 2 && t2 == 2 && t3 == 4) || (njf == 10 && t1 == 4 && t2 == 4 && t3 == 8) ||
            (njf == 4 && t1 == 4 && t2 == 4 && t3 == 8);
@@ -1105,6 +1126,7 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
     const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32;
     hipStream_t st = as_stream(stream);
     if (njf == 0 && t2 == 2) return launch_sa_chain<0, 2, 2, 4>(p, st);
+    if (njf == 0 && t2 == 3) return launch_sa_chain<0, 2, 3, 4>(p, st);
     if (njf == 0) return launch_sa_chain<0, 2, 4, 4>(p, st);
     if (njf == 10 && t1 == 2) return launch_sa_chain<10, 2, 2, 4>(p, st);
     if (njf == 10) return launch_sa_chain<10, 4, 4, 8>(p, st);

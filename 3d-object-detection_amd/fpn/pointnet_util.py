@@ -109,8 +109,16 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     store until its variables change."""
     if len(widths) != 3:
         return None
-    pad = (_round_up(widths[0], 64), _round_up(widths[1], 64), _round_up(widths[2], 128))
-    if not _lib.load().fpn_sa_chain_supported(cf, *pad):
+    # padded widths: the middle layer to a multiple of 32 where a kernel exists for that
+    # (96 stays 96), else of 64
+    pad = None
+    for mid in (32, 64):
+        cand = (_round_up(widths[0], 64), _round_up(widths[1], mid), _round_up(widths[2], 128))
+        if SA_PRECISION != "bf16" or mid == 64:        # (the bf16 streams pair output tiles: multiples of 64)
+            if _lib.load().fpn_sa_chain_supported(cf, *cand):
+                pad = cand
+                break
+    if pad is None:
         # the variables are created by the per-layer path
         return None
     cache = store.__dict__.setdefault("_sa_chain_cache", {})

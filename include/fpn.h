@@ -357,7 +357,8 @@ int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const floa
  * fpn_v1_seg_tail_f32); the (b,m,nsample,3+cf) grouped tensor is never written.
  *   xyz (b,n,3), new_xyz (b,m,3), feat (b,n,cf) or NULL, idx (b,m,ns) from
  *   fpn_query_ball_point; ns % 32 == 0.
- *   Layer widths c1, c2 (multiples of 64) and c3 (multiple of 128) are the PADDED
+ *   Layer widths c1, c2 (multiples of 64; c2 = 96 is also built for the c1 = 64, c3 = 128,
+ *   cf < 32 shape) and c3 (multiple of 128) are the PADDED
  *   widths: a narrower layer is padded by the caller with zero weight columns and
  *   zero scale / shift.  layers: HOST array of 9 device pointers {w,scale,shift} x 3:
  *     cf < 32 : w1 row-major (3+cf, c1), rows ordered [dx,dy,dz, features];
