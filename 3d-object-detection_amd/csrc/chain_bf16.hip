@@ -21,16 +21,22 @@
 // so that the kernel can always read a fixed number of units ahead - across layer
 // boundaries - through a ring of registers.
 //
-// What sets the pace is not the matrix pipe but the delivery of weight fragments into
-// registers: every MFMA needs 1 KiB of them, four waves at the MFMA's pace would pull
-// 128 bytes per clock through the CU's vector memory path, which delivers 64 (measured on
-// the seg tail: 0.56 ms as is, 0.30 ms with the re-loads removed; ring depth and
-// occupancy change nothing; staging each unit once per workgroup in LDS was slower, 0.64
-// ms - the LDS read path is no wider for this access pattern and the stage barriers
-// cost).  So where the registers allow, a wave carries NP = 2 groups of 32 points and
-// uses every fragment twice.
+// Weight delivery.  Every MFMA needs 1 KiB of weight fragments; four waves at the MFMA's
+// pace, each reading the stream for itself, would pull 128 bytes per clock through the
+// CU's vector memory path, which delivers 64.  So where the registers allow, a wave
+// carries NP = 2 groups of 32 points and uses every fragment twice (then the weight reads
+// cost 10-15 % of the kernel: seg head 0.31 ms against 0.27 ms with the loads removed and
+// the fragments kept opaque to the compiler, box chain 0.17 against 0.15).  The seg tail
+// cannot (conv6's output fills the registers) and takes its units through a ring in LDS
+// that its workgroup fills once (CoopFeed below): 0.57 -> 0.50 ms.  With no weight
+// movement at all the tail takes 0.37 ms, twice its MFMA time: one wave per SIMD issues
+// in order, and every epilogue, wait and barrier is a bubble in the matrix pipe.
+// (A timing build that removes loads must keep the fragments opaque - FPN_RING_NOLOAD,
+// FPN_FEED_NO* below - or the compiler merges the MFMAs that now see equal operands.)
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <string>
 #include <type_traits>
 #include <utility>
 
@@ -74,6 +80,135 @@ __device__ __forceinline__ void load_unit(WUnit &u, const bf16x8 *__restrict__ p
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int m = 0; m < 2; ++m) u.w[a][m] = p[(a * 2 + m) * 64 + lane];
+}
+
+// Where a wave's weight units come from.  Both feeds hand out the unit of stream position
+// PH (mod 4) and are advanced once per unit, right after the unit's MFMAs are issued.
+//
+// RingFeed: the wave reads the stream itself, kRing units ahead, 4 KiB per unit through
+// the vector memory path - with four waves at the MFMA's pace that path (64 bytes a clock
+// per CU) is the limit as soon as a fragment is used once only (NP = 1).
+//
+// CoopFeed: the four waves of a workgroup walk the SAME stream, so each unit crosses the
+// vector memory path once per workgroup - every wave fetches a quarter of it (one 16-byte
+// load per lane), parks it in registers for kFeedStage units, writes it into a ring of
+// kFeedSlots units in LDS, and all four read their fragments from there (ds_read_b128,
+// 256 bytes a clock per CU).  Unit x is written during step x - kFeedAhead, read into
+// registers during step x - kFeedRead and multiplied in step x; a workgroup barrier stands
+// before every even step, which puts one between the write and the read of a unit and one
+// between the last read of a slot and its next write.  Needs every wave of the workgroup
+// alive and on the same stream.
+constexpr int kFeedSlots = 4, kFeedAhead = 4, kFeedRead = 2, kFeedStage = 4;
+static_assert(kFeedAhead + kFeedStage < kPadUnits, "read-ahead exceeds the stream's padding");
+
+// (timing-only builds) the compiler may assume nothing about the unit's registers
+__device__ __forceinline__ void opaque(WUnit &u)
+{
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(u.w[a][m]));
+}
+
+struct RingFeed {
+    static constexpr bool kCoop = false;
+    WUnit ring[kRing];
+    unsigned lane;
+    __device__ __forceinline__ void start(const bf16x8 *__restrict__ ws, unsigned lane_, bf16x8 *)
+    {
+        lane = lane_;
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
+    }
+    template <int PH>
+    __device__ __forceinline__ const WUnit &cur() const { return ring[PH % kRing]; }
+    // unit: the unit being multiplied; its slot is refilled with the unit kRing further on
+    template <int PH>
+    __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
+    {
+#ifndef FPN_RING_NOLOAD
+        load_unit(ring[PH % kRing], unit + (size_t)kRing * kUnitVecs, lane);
+#else       // timing-only build (wrong results): no loads; the fragments stay opaque so that every MFMA remains
+        opaque(ring[PH % kRing]);
+#endif
+    }
+    template <int PH>
+    __device__ __forceinline__ void sync() {}
+};
+
+struct CoopFeed {
+    static constexpr bool kCoop = true;
+    WUnit frag[4];          // (indexed by stream position mod 4; kFeedRead + 1 of them are live)
+    bf16x8 stage[kFeedStage];
+    bf16x8 *lds;            // kFeedSlots * kUnitVecs vectors, shared by the workgroup
+    unsigned lane, mine;    // mine: this lane's vector of a unit's quarter
+    template <int SLOT>
+    __device__ __forceinline__ void read_unit(WUnit &u) const
+    {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) u.w[a][m] = lds[SLOT * kUnitVecs + (a * 2 + m) * 64 + lane];
+    }
+    __device__ __forceinline__ void read_unit_rt(WUnit &u, int slot) const
+    {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) u.w[a][m] = lds[slot * kUnitVecs + (a * 2 + m) * 64 + lane];
+    }
+    __device__ __forceinline__ void start(const bf16x8 *__restrict__ ws, unsigned lane_, bf16x8 *ring)
+    {
+        lane = lane_;
+        lds = ring;
+        mine = (threadIdx.x >> 6) * 64 + lane_;
+        bf16x8 first[kFeedAhead];
+#pragma unroll
+        for (int i = 0; i < kFeedAhead; ++i) first[i] = ws[(size_t)i * kUnitVecs + mine];
+#pragma unroll
+        for (int i = 0; i < kFeedStage; ++i) stage[i] = ws[(size_t)(kFeedAhead + i) * kUnitVecs + mine];
+#pragma unroll
+        for (int i = 0; i < kFeedAhead; ++i) lds[i * kUnitVecs + mine] = first[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kFeedRead; ++i) read_unit_rt(frag[i], i);
+        __syncthreads();
+    }
+    template <int PH>
+    __device__ __forceinline__ const WUnit &cur() const { return frag[PH % 4]; }
+    template <int PH>
+    __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
+    {
+        // (FPN_FEED_NO*: timing-only builds that drop one part of the feed; wrong results)
+#ifndef FPN_FEED_NOREAD
+        read_unit<(PH + kFeedRead) % kFeedSlots>(frag[(PH + kFeedRead) % 4]);
+#else
+        opaque(frag[(PH + kFeedRead) % 4]);
+#endif
+#ifndef FPN_FEED_NOFILL
+        lds[((PH + kFeedAhead) % kFeedSlots) * kUnitVecs + mine] = stage[PH % kFeedStage];
+        stage[PH % kFeedStage] = unit[(size_t)(kFeedAhead + kFeedStage) * kUnitVecs + mine];
+#endif
+    }
+    template <int PH>
+    __device__ __forceinline__ void sync()
+    {
+#ifndef FPN_FEED_NOBAR
+        if constexpr (PH % 2 == 1) __syncthreads();
+#endif
+    }
+};
+
+// the workgroup's unit ring in LDS (CoopFeed), none for RingFeed
+template <class Feed>
+__device__ __forceinline__ bf16x8 *feed_ring()
+{
+    if constexpr (Feed::kCoop) {
+        __shared__ bf16x8 wring[kFeedSlots * kUnitVecs];
+        return wring;
+    } else {
+        return nullptr;
+    }
 }
 
 // per-channel constants of a lane for one 32-channel tile: channels ch0 + 8q + i
@@ -150,13 +285,22 @@ __device__ __forceinline__ void unit_mfma(floatx16 (&acc)[2][NP], const WUnit &u
 // after each MFMA come one memory read (while there are any, NVMEM of them) and up to
 // NVALU vector-ALU instructions - they issue in the 32 cycles the MFMA occupies the pipe;
 // nothing crosses the end of the unit.
-template <int NMFMA, int NVMEM, int NVALU>
+// COOP (CoopFeed): the unit's four weight loads are one load, four LDS reads and one LDS
+// write instead, all placed behind the unit's FIRST MFMA: the barrier that may end the
+// unit waits for every LDS operation of the wave, so they get the rest of the unit's MFMAs
+// to complete in.
+template <bool COOP, int NMFMA, int NVMEM, int NVALU>
 __device__ __forceinline__ void sched_unit()
 {
+    constexpr int NV = COOP ? NVMEM - 3 : NVMEM;
 #pragma unroll
     for (int m = 0; m < NMFMA; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (m < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, (NVMEM + NMFMA - 1) / NMFMA, 0);
+        if (COOP && m == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        if (m < NV) __builtin_amdgcn_sched_group_barrier(0x020, (NV + NMFMA - 1) / NMFMA, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -167,9 +311,9 @@ __device__ __forceinline__ void sched_unit()
 // (R0 + i) % kRing = unit i) and the first kRing units after the layer on exit.  The
 // epilogue of a pair rides on the first two units of the next pair; the last one is
 // exposed.  Out: Act (bf16 operand) or floatx16 (fp32).
-template <int NP, int NJ, int NT, int R0, class Out>
+template <int NP, int NJ, int NT, int R0, class Out, class Feed>
 __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
-                                        const float *__restrict__ sh, WUnit (&ring)[kRing], unsigned lane, int h)
+                                        const float *__restrict__ sh, Feed &feed, int h)
 {
     static_assert(NJ >= 2 && NT % 2 == 0, "unsupported layer shape");
     constexpr int U = (NT / 2) * NJ;
@@ -178,8 +322,8 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
     static_for<0, U>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
         constexpr int slot = (R0 + S) % kRing;
-        unit_mfma<j == 0, true, j>(acc[set], ring[slot], in);
-        load_unit(ring[slot], ws + (size_t)(S + kRing) * kUnitVecs, lane);
+        unit_mfma<j == 0, true, j>(acc[set], feed.template cur<slot>(), in);
+        feed.template advance<slot>(ws + (size_t)S * kUnitVecs);
         if constexpr (tp > 0 && j < 2) {
 #pragma unroll
             for (int g = 0; g < NP; ++g) finish(out[g][2 * (tp - 1) + j], acc[set ^ 1][j][g], csh[j]);
@@ -188,7 +332,8 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
             load_const(csh[0], sh, 32 * (2 * tp) + 4 * h);
             load_const(csh[1], sh, 32 * (2 * tp + 1) + 4 * h);
         }
-        sched_unit<4 * NP, j == NJ - 1 ? 12 : 4, (tp > 0 && j < 2) ? (48 * NP + 4 * NP - 1) / (4 * NP) : 1>();
+        sched_unit<Feed::kCoop, 4 * NP, j == NJ - 1 ? 12 : 4, (tp > 0 && j < 2) ? (48 * NP + 4 * NP - 1) / (4 * NP) : 1>();
+        feed.template sync<slot>();
     });
     constexpr int last = (NT / 2 - 1) & 1;
 #pragma unroll
@@ -282,9 +427,9 @@ __device__ __forceinline__ void wg_pool_flush(int (&lmax)[4 * C], const WgPool &
 // relu(in . W' + shift)), four output tiles per trip of a rolled loop; the reduction of
 // one pair rides on the units of the next.  Channels >= cvalid (widths padded up to a
 // multiple of 128) are not written.
-template <int NP, int NJ, int NT, int R0>
+template <int NP, int NJ, int NT, int R0, class Feed>
 __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
-                                          const float *__restrict__ sh, int *gmax, WUnit (&ring)[kRing], unsigned lane,
+                                          const float *__restrict__ sh, int *gmax, Feed &feed, unsigned lane,
                                           int cvalid = 32 * NT)
 {
     static_assert(NJ >= 2 && NT % 4 == 0 && (2 * NJ) % kRing == 0, "unsupported layer shape");
@@ -303,8 +448,8 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
         static_for<0, 2 * NJ>([&](auto I) {
             constexpr int S = decltype(I)::value, set = S / NJ, j = S % NJ;
             constexpr int slot = (R0 + S) % kRing;
-            unit_mfma<j == 0, false, j>(acc[set], ring[slot], in);
-            load_unit(ring[slot], wt + (size_t)(S + kRing) * kUnitVecs, lane);
+            unit_mfma<j == 0, false, j>(acc[set], feed.template cur<slot>(), in);
+            feed.template advance<slot>(wt + (size_t)S * kUnitVecs);
             // the other accumulator pair holds the two tiles before these; the very first
             // time there are none (it holds zeros, and so does the shift): the update is
             // then a harmless max with 0 - no branch inside the unit
@@ -317,7 +462,8 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
                 rsh[0] = sh[32 * tcur + c];
                 rsh[1] = sh[32 * (tcur + 1) + c];
             }
-            sched_unit<4 * NP, j == NJ - 1 ? 6 : 4, j < 2 ? (12 * NP + 8 + 4 * NP - 1) / (4 * NP) : 1>();
+            sched_unit<Feed::kCoop, 4 * NP, j == NJ - 1 ? 6 : 4, j < 2 ? (12 * NP + 8 + 4 * NP - 1) / (4 * NP) : 1>();
+            feed.template sync<slot>();
         });
     }
     if (32 * (NT - 2) < cvalid) {
@@ -356,12 +502,6 @@ __device__ __forceinline__ void layer_first(Act (&out)[NT], const float (&x)[NST
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void fill_ring(WUnit (&ring)[kRing], const bf16x8 *__restrict__ ws, unsigned lane)
-{
-#pragma unroll
-    for (int i = 0; i < kRing; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
-}
-
 constexpr int units_of(int cin, int cout) { return (cout / 64) * (cin / 32); }
 
 // ---------------------------------------------------------------------------
@@ -383,7 +523,7 @@ struct HeadParams {
     long copy_vecs;     // > 0: one stream (and one w1) per frustum, this many 16-byte vectors apart
 };
 
-template <int NP>
+template <int NP, class Feed = RingFeed>
 __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
@@ -402,8 +542,8 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     if (pool.on) wg_pool_clear<1024>(lmax, pool);
     int *gmax = reinterpret_cast<int *>(p.gmax + (row0 / p.n) * p.ldg);
 
-    WUnit ring[kRing];
-    fill_ring(ring, p.ws, lane);
+    Feed feed;
+    feed.start(p.ws, lane, feed_ring<Feed>());
     Act a1[NP][2], a2[NP][2], a3[NP][2], a4[NP][4];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
@@ -415,9 +555,9 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     }
     constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
     const bf16x8 *ws = p.ws;
-    layer_t<NP, 2, 2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+    layer_t<NP, 2, 2, 0>(a2, a1, ws, p.sh2, feed, h);
     ws += U2 * kUnitVecs;
-    layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws, p.sh3, ring, lane, h);
+    layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws, p.sh3, feed, h);
     ws += U3 * kUnitVecs;
 #pragma unroll
     for (int g = 0; g < NP; ++g)
@@ -425,13 +565,13 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h] = a3[g][t].m[s];
-    layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, p.sh4, ring, lane, h);
+    layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, p.sh4, feed, h);
     ws += U4 * kUnitVecs;
     if (pool.on) {      // (two copies of the layer: LDS and memory atomics are different instructions)
-        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, lmax + pool.local * 1024, ring, lane);
+        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, lmax + pool.local * 1024, feed, lane);
         wg_pool_flush<1024>(lmax, pool, p.gmax, p.ldg, 1024);
     } else {
-        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, gmax, ring, lane);
+        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, gmax, feed, lane);
     }
 }
 
@@ -453,12 +593,13 @@ struct TailParams {
     const unsigned *drop;                // (rows,4) keep bits of conv9's outputs, or NULL
 };
 
+template <class Feed>
 __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)logical_block(pin.copy_vecs) * kWaves + (threadIdx.x >> 6)) * 32;
-    if (row0 >= pin.rows) return;
+    if (row0 >= pin.rows) return;       // (never with a cooperative feed: the host launches it on full workgroups only)
     TailParams p = pin;
     if (pin.copy_vecs) {
         const size_t f = scalar_index(row0 / pin.n);
@@ -466,8 +607,8 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
         p.w10 += f * (128 * 2);
     }
 
-    WUnit ring[kRing];
-    fill_ring(ring, p.ws, lane);
+    Feed feed;
+    feed.start(p.ws, lane, feed_ring<Feed>());
     Act pf[1][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -478,13 +619,13 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
     const bf16x8 *ws = p.ws;
     Act a6[1][16], a7[1][8], a8[1][4];
     floatx16 a9[1][4];
-    layer_t<1, 2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, ring, lane, h);
+    layer_t<1, 2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, feed, h);
     ws += U6 * kUnitVecs;
-    layer_t<1, 16, 8, U6 % kRing>(a7, a6, ws, p.sh7, ring, lane, h);
+    layer_t<1, 16, 8, U6 % kRing>(a7, a6, ws, p.sh7, feed, h);
     ws += U7 * kUnitVecs;
-    layer_t<1, 8, 4, (U6 + U7) % kRing>(a8, a7, ws, p.sh8, ring, lane, h);
+    layer_t<1, 8, 4, (U6 + U7) % kRing>(a8, a7, ws, p.sh8, feed, h);
     ws += U8 * kUnitVecs;
-    layer_t<1, 4, 4, (U6 + U7 + U8) % kRing>(a9, a8, ws, p.sh9, ring, lane, h);
+    layer_t<1, 4, 4, (U6 + U7 + U8) % kRing>(a9, a8, ws, p.sh9, feed, h);
 
     // Monte-Carlo dropout before the head (models/FPointNet_Bayes.py:92): bit c of word j
     // of the point's mask keeps channel 32 j + c, kept activations count twice
@@ -531,7 +672,7 @@ struct ObjParams {
     long copy_vecs;                    // > 0: one stream (and one w1) per frustum
 };
 
-template <bool BOX, int NP>
+template <bool BOX, int NP, class Feed = RingFeed>
 __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjParams pin)
 {
     const unsigned lane = threadIdx.x & 63;
@@ -552,8 +693,8 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     const long frustum = row0 / p.m;
     int *gmax = reinterpret_cast<int *>(p.gmax + frustum * p.ldg);
 
-    WUnit ring[kRing];
-    fill_ring(ring, p.ws, lane);
+    Feed feed;
+    feed.start(p.ws, lane, feed_ring<Feed>());
     Act a1[NP][4], a2[NP][4];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
@@ -568,17 +709,17 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     }
     constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
     const bf16x8 *ws = p.ws;
-    layer_t<NP, 4, 4, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+    layer_t<NP, 4, 4, 0>(a2, a1, ws, p.sh2, feed, h);
     ws += U2 * kUnitVecs;
     if constexpr (!BOX) {
-        if (pool.on) layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane);
-        else layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, gmax, ring, lane);
+        if (pool.on) layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane);
+        else layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, gmax, feed, lane);
     } else {
         Act a3[NP][8];
-        layer_t<NP, 4, 8, U2 % kRing>(a3, a2, ws, p.sh3, ring, lane, h);
+        layer_t<NP, 4, 8, U2 % kRing>(a3, a2, ws, p.sh3, feed, h);
         ws += U3 * kUnitVecs;
-        if (pool.on) layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, lmax + pool.local * C, ring, lane);
-        else layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, gmax, ring, lane);
+        if (pool.on) layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, lmax + pool.local * C, feed, lane);
+        else layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, gmax, feed, lane);
     }
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.gmax, p.ldg, C);
 }
@@ -603,7 +744,7 @@ struct SaParams {
     int ldo, c3;
 };
 
-template <int NJF, int NT1, int NT2, int NT3, int NP>
+template <int NJF, int NT1, int NT2, int NT3, int NP, class Feed = RingFeed>
 __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaParams p)
 {
     const unsigned lane = threadIdx.x & 63;
@@ -620,8 +761,8 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
     const float *ctr = p.new_xyz + ball * 3;
     int *gmax = reinterpret_cast<int *>(p.out + ball * p.ldo);
 
-    WUnit ring[kRing];
-    fill_ring(ring, p.ws, lane);
+    Feed feed;
+    feed.start(p.ws, lane, feed_ring<Feed>());
     const bf16x8 *ws = p.ws;
     Act a1[NP][NT1], a2[NP][NT2];
     if constexpr (NJF > 0) {
@@ -653,12 +794,12 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int U1 = (NT1 / 2) * NJ1, U2 = (NT2 / 2) * NT1;
-        layer_t<NP, NJ1, NT1, 0>(a1, in, ws, p.shs1, ring, lane, h);
+        layer_t<NP, NJ1, NT1, 0>(a1, in, ws, p.shs1, feed, h);
         ws += U1 * kUnitVecs;
-        layer_t<NP, NT1, NT2, U1 % kRing>(a2, a1, ws, p.sh2, ring, lane, h);
+        layer_t<NP, NT1, NT2, U1 % kRing>(a2, a1, ws, p.sh2, feed, h);
         ws += U2 * kUnitVecs;
-        if (pool.on) layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
-        else layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+        if (pool.on) layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane, p.c3);
+        else layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, gmax, feed, lane, p.c3);
     } else {
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
@@ -676,10 +817,10 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
             layer_first<NT1, 4>(a1[g], x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
         }
         constexpr int U2 = (NT2 / 2) * NT1;
-        layer_t<NP, NT1, NT2, 0>(a2, a1, ws, p.sh2, ring, lane, h);
+        layer_t<NP, NT1, NT2, 0>(a2, a1, ws, p.sh2, feed, h);
         ws += U2 * kUnitVecs;
-        if (pool.on) layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, ring, lane, p.c3);
-        else layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, gmax, ring, lane, p.c3);
+        if (pool.on) layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane, p.c3);
+        else layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, gmax, feed, lane, p.c3);
     }
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
 }
@@ -700,7 +841,7 @@ struct FpHeadParams {
     float *logits;
 };
 
-template <int NJA, int NP>
+template <int NJA, int NP, class Feed = RingFeed>
 __global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadParams p)
 {
     constexpr int NJ = NJA + 1;
@@ -709,8 +850,8 @@ __global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadP
     const long row0 = ((long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     if (row0 >= p.rows) return;
 
-    WUnit ring[kRing];
-    fill_ring(ring, p.ws, lane);
+    Feed feed;
+    feed.start(p.ws, lane, feed_ring<Feed>());
     Act in[NP][NJ], a1[NP][4], a2[NP][4];
     floatx16 a3[NP][4];
 #pragma unroll
@@ -736,11 +877,11 @@ __global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadP
     __builtin_amdgcn_sched_barrier(0);
     constexpr int U1 = 2 * NJ, U2 = 2 * 4;
     const bf16x8 *ws = p.ws;
-    layer_t<NP, NJ, 4, 0>(a1, in, ws, p.sh1, ring, lane, h);
+    layer_t<NP, NJ, 4, 0>(a1, in, ws, p.sh1, feed, h);
     ws += U1 * kUnitVecs;
-    layer_t<NP, 4, 4, U1 % kRing>(a2, a1, ws, p.sh2, ring, lane, h);
+    layer_t<NP, 4, 4, U1 % kRing>(a2, a1, ws, p.sh2, feed, h);
     ws += U2 * kUnitVecs;
-    layer_t<NP, 4, 4, (U1 + U2) % kRing>(a3, a2, ws, p.sh3, ring, lane, h);
+    layer_t<NP, 4, 4, (U1 + U2) % kRing>(a3, a2, ws, p.sh3, feed, h);
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
         float s0 = 0.f, s1 = 0.f;
@@ -821,6 +962,22 @@ __global__ __launch_bounds__(256) void flipout_units_kernel(long copies, int cin
         for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaf(d[e], si[8 * (e >> 2) + (e & 3)] * so, m[e]);
         dst[f * copy_vecs + v] = o;
     }
+}
+
+// FPN_BF16_FEED=ring keeps every wave on its own weight stream (a measurement switch)
+inline bool coop_feed()
+{
+    const char *e = std::getenv("FPN_BF16_FEED");
+    return !(e && std::string(e) == "ring");
+}
+
+// The cooperative feed needs every wave of every workgroup alive (rows fill the workgroups)
+// and on one stream (a workgroup's rows inside one frustum copy when the copies have their
+// own streams).  group: rows per copy.
+inline bool use_coop(long rows, int np, long copy_vecs, long group)
+{
+    const long wg_rows = (long)kWaves * 32 * np;
+    return coop_feed() && rows % wg_rows == 0 && (copy_vecs == 0 || group % wg_rows == 0);
 }
 
 inline dim3 grid_for(long rows, int np)
@@ -910,6 +1067,8 @@ int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void 
     p.sh2 = consts[3]; p.sh3 = consts[4]; p.sh4 = consts[5]; p.sh5 = consts[6];
     p.point_feat = reinterpret_cast<bf16x8 *>(point_feat); p.gmax = global_max; p.ldg = ldg;
     p.copy_vecs = copy_vecs;
+    // (the cooperative feed was measured here too: 0.43 -> 0.41 ms with one stream per frustum copy, nothing
+    // with a shared stream: two point groups per wave already use every fragment twice)
     if (groups_per_wave(n) == 2)
         hipLaunchKernelGGL(seg_head_bf16_kernel<2>, grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
     else
@@ -934,7 +1093,10 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
     p.logits = logits;
     p.copy_vecs = copy_vecs;
     p.drop = reinterpret_cast<const unsigned *>(drop_mask);
-    hipLaunchKernelGGL(seg_tail_bf16_kernel, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+    if (use_coop(rows, 1, copy_vecs, n))
+        hipLaunchKernelGGL(seg_tail_bf16_kernel<CoopFeed>, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL(seg_tail_bf16_kernel<RingFeed>, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
     return check_launch("fpn_v1_seg_tail_bf16");
 }
 

@@ -40,7 +40,7 @@ def get_instance_seg_v2_net(point_cloud, one_hot_vec, is_training, bn_decay, end
                                    scope='fa_layer1')
     l1_points = pointnet_fp_module(l1_xyz, l2_xyz, l1_points, l2_points, s["fp2"], is_training, bn_decay,
                                    scope='fa_layer2')
-    l0_feat = torch.cat([l0_xyz, l0_points], dim=-1) if l0_points is not None else l0_xyz
+    l0_feat = point_cloud if l0_points is not None else l0_xyz      # = [l0_xyz | l0_points]
     # last feature propagation + conv1d(128) + dropout (identity at inference, keep_prob
     # s["dropout_keep"] in training) + conv1d(2): one kernel when the shapes fit
     logits = pointnet_fp_module_with_head(l0_xyz, l1_xyz, l0_feat, l1_points, s["fp3"], 128, 2, is_training,

@@ -69,12 +69,28 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     return new_xyz, new_points, idx, grouped_xyz
 
 
+_GROUP_ALL_CONSTANTS = {}
+
+
+def _group_all_constants(b, n, device):
+    """The centroid (0,0,0) and the index table 0..n-1 of sample_and_group_all: the same
+    for every call of a shape, so they are made once (read-only by convention)."""
+    key = (b, n, device)
+    hit = _GROUP_ALL_CONSTANTS.get(key)
+    if hit is None:
+        if len(_GROUP_ALL_CONSTANTS) >= 64:
+            _GROUP_ALL_CONSTANTS.clear()
+        hit = (torch.zeros((b, 1, 3), dtype=torch.float32, device=device),
+               torch.arange(n, dtype=torch.int32, device=device).reshape(1, 1, n).expand(b, 1, n))
+        _GROUP_ALL_CONSTANTS[key] = hit
+    return hit
+
+
 def sample_and_group_all(xyz, points, use_xyz=True):
     """Reference: pointnet_util.py:58-83: one group holding every point, centroid (0,0,0),
     no translation."""
     b, n, _ = xyz.shape
-    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
-    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).expand(b, 1, n)
+    new_xyz, idx = _group_all_constants(b, n, xyz.device)
     grouped_xyz = xyz.reshape(b, 1, n, 3)
     if points is not None:
         new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
@@ -169,10 +185,11 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     return plan
 
 
-def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first):
+def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first, zeroed=False):
     """Grouping + 3-layer MLP + max over the samples in one kernel (fpn_sa_chain_f32).
-    out2d (b*m, widths[-1]) may be a column slice of a wider buffer.  Returns False when
-    the shape has no fused kernel (the caller then runs the per-layer path)."""
+    out2d (b*m, widths[-1]) may be a column slice of a wider buffer; the kernel merges its
+    maxima into it, so it must start at zero (`zeroed`: the caller has cleared it).  Returns
+    False when the shape has no fused kernel (the caller then runs the per-layer path)."""
     b, n, _ = xyz.shape
     _, m, ns = idx.shape
     cf = 0 if points is None else points.shape[2]
@@ -183,7 +200,8 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
     plan = _sa_chain_plan(store, names, cf, widths, bn, xyz_first)
     if plan is None:
         return False
-    out2d.zero_()
+    if not zeroed:
+        out2d.zero_()
     pad = plan["pad"]
     ldo = out2d.stride(0) if out2d.shape[0] > 1 else max(out2d.stride(0), out2d.shape[1])
     obs = ops.launch_observer
@@ -281,14 +299,16 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
         b, m = new_xyz.shape[0], new_xyz.shape[1]
         width = sum(w[-1] for w in mlp_list)
-        out = torch.empty((b * m, width), dtype=torch.float32, device=xyz.device)
+        # (one clear for all scales: the fused kernels merge their maxima into it)
+        out = torch.zeros((b * m, width), dtype=torch.float32, device=xyz.device)
         col = 0
         for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
             idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
             w_i = mlp_list[i][-1]
             if (points is None or use_xyz) and FUSE_SA and \
                     _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx, mlp_list[i],
-                              'conv%d_' % i + '%d', bn, out[:, col:col + w_i], xyz_first=False):   # :176-192 in one kernel
+                              'conv%d_' % i + '%d', bn, out[:, col:col + w_i], xyz_first=False,
+                              zeroed=True):                                                      # :176-192 in one kernel
                 col += w_i
                 continue
             if points is not None and use_xyz:

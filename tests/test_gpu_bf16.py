@@ -248,3 +248,26 @@ def test_bf16_v2_single_frustum(device):
         pointnet_util.SA_PRECISION = old
     err = scaled_err(got, want)
     assert 1e-6 < err <= BF16_RTOL, err
+
+
+@pytest.mark.parametrize("B,N,dropout", [(4, 256, False), (16, 1024, True), (13, 96, True)])
+def test_bf16_weight_feeds_agree_bit_for_bit(device, monkeypatch, B, N, dropout):
+    """The seg tail takes its weight units either through each wave's own register ring or
+    through the workgroup's ring in LDS (full workgroups on one stream; 13 x 96 stays on the
+    register ring either way): same arithmetic in the same order, so the same bits - shared
+    stream (plain v1) and one stream per frustum copy (Flipout)."""
+    from fpn import bayes, synthetic, variables
+    st = variables.VariableStore(device, seed=4)
+    bp = bayes.BayesPlan(st, 3, mc_dropout=dropout, precision="bf16")
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=B)
+    pcd, ohd = dev(pc, device), dev(oh, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    noise = bp.sample_noise(2, B, g, N)
+    got = {}
+    for feed in ("ring", "lds"):
+        monkeypatch.setenv("FPN_BF16_FEED", feed)
+        ep = bp.forward(pcd, ohd, 2, noise=noise)
+        got[feed] = {k: ep[k].clone() for k in ("mask_logits", "box_output", "stage1_center")}
+    for k in got["ring"]:
+        assert torch.equal(got["ring"][k], got["lds"][k]), k
