@@ -476,31 +476,62 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
 // instruction: out[NT] = relu(scale * (W1^T . x^T) + shift) as bf16 operands.  x: the
 // lane's inputs for MFMA steps 0..NSTEP-1, i.e. channels 2s + h of its point (zero beyond
 // the channel count); w1 (K, 32 NT) row-major fp32.
+//
+// The layer's weights and constants are the same for every point group of the wave and
+// depend on nothing the kernel computes: FirstLayer::load is issued BEFORE the kernel
+// gathers its inputs, so that the two memory latencies overlap (a wave per SIMD hides
+// nothing by itself: measured on the set-abstraction kernel, 5.6 k of a wave's 13.2 k
+// cycles went into this layer when its loads sat between the MFMAs).
 template <int NT, int NSTEP>
-__device__ __forceinline__ void layer_first(Act (&out)[NT], const float (&x)[NSTEP], const float *__restrict__ w1,
-                                            int k_total, const float *__restrict__ sc, const float *__restrict__ sh,
-                                            unsigned lane, int h)
-{
-    const int c = lane & 31;
+struct FirstLayer {
+    float wv[NT][NSTEP];
+    TileConst csc[NT], csh[NT];
+
+    __device__ __forceinline__ void load(const float *__restrict__ w1, int k_total, const float *__restrict__ sc,
+                                         const float *__restrict__ sh, unsigned lane, int h)
+    {
+        const int c = lane & 31;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        floatx16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            const int k = 2 * s + h;
-            const float wv = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
-            a = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, x[s], a, 0, 0, 0);
+            for (int s = 0; s < NSTEP; ++s) {
+                const int k = 2 * s + h;
+                wv[t][s] = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
+            }
+            load_const(csc[t], sc, 32 * t + 4 * h);
+            load_const(csh[t], sh, 32 * t + 4 * h);
         }
-        TileConst csc, csh;
-        load_const(csc, sc, 32 * t + 4 * h);
-        load_const(csh, sh, 32 * t + 4 * h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            out[t].m[r >> 3][r & 7] =
-                (__bf16)fmaxf(fmaf(a[r], comp(csc.q[r >> 2], r & 3), comp(csh.q[r >> 2], r & 3)), 0.f);
     }
-    __builtin_amdgcn_sched_barrier(0);
-}
+
+    // relu(acc * scale + shift) -> bf16: packed multiply-add, packed conversion, the clamp as a
+    // packed 16-bit integer max on the bit patterns (as finish() above)
+    __device__ __forceinline__ void apply(Act (&out)[NT], const float (&x)[NSTEP]) const
+    {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            floatx16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], x[s], a, 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                shortx8 bits;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const int r = 8 * f + e;
+                    const floatx2 y = __builtin_elementwise_fma(
+                        floatx2{a[r], a[r + 1]}, floatx2{comp(csc[t].q[r >> 2], r & 3), comp(csc[t].q[r >> 2], (r & 3) + 1)},
+                        floatx2{comp(csh[t].q[r >> 2], r & 3), comp(csh[t].q[r >> 2], (r & 3) + 1)});
+                    const shortx2 v = __builtin_elementwise_max(
+                        __builtin_bit_cast(shortx2, __builtin_convertvector(y, bf16x2)), shortx2{0, 0});
+                    bits[e] = v[0];
+                    bits[e + 1] = v[1];
+                }
+                out[t].m[f] = __builtin_bit_cast(bf16x8, bits);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
 
 constexpr int units_of(int cin, int cout) { return (cout / 64) * (cin / 32); }
 
@@ -545,13 +576,18 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     Feed feed;
     feed.start(p.ws, lane, feed_ring<Feed>());
     Act a1[NP][2], a2[NP][2], a3[NP][2], a4[NP][4];
+    {
+        FirstLayer<2, 4> first;
+        first.load(p.w1, p.cpc, p.sc1, p.sh1, lane, h);
+        float x[NP][4];
 #pragma unroll
-    for (int g = 0; g < NP; ++g) {
-        float x[4];
-        const float *src = p.pc + (row0 + 32 * g + pt) * p.cpc;
+        for (int g = 0; g < NP; ++g) {
+            const float *src = p.pc + (row0 + 32 * g + pt) * p.cpc;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) x[s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
-        layer_first<2, 4>(a1[g], x, p.w1, p.cpc, p.sc1, p.sh1, lane, h);
+            for (int s = 0; s < 4; ++s) x[g][s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
     }
     constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
     const bf16x8 *ws = p.ws;
@@ -696,16 +732,21 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     Feed feed;
     feed.start(p.ws, lane, feed_ring<Feed>());
     Act a1[NP][4], a2[NP][4];
+    {
+        FirstLayer<4, 2> first;
+        first.load(p.w1, 3, p.sc1, p.sh1, lane, h);
+        float x[NP][2];
 #pragma unroll
-    for (int g = 0; g < NP; ++g) {
-        float x[2];
-        const float *src = p.obj + (row0 + 32 * g + pt) * 3;
+        for (int g = 0; g < NP; ++g) {
+            const float *src = p.obj + (row0 + 32 * g + pt) * 3;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int k = 2 * s + h;
-            x[s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * s + h;
+                x[g][s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
+            }
         }
-        layer_first<4, 2>(a1[g], x, p.w1, 3, p.sc1, p.sh1, lane, h);
+#pragma unroll
+        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
     }
     constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
     const bf16x8 *ws = p.ws;
@@ -732,6 +773,9 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
 // ((NJF+1)*32 rows), layer 2, layer 3.  NJF = 0: first layer in fp32 from memory; stream:
 // layer 2, layer 3.
 // ---------------------------------------------------------------------------
+#ifndef FPN_SA_OCC
+#define FPN_SA_OCC(njf) 1
+#endif
 struct SaParams {
     long rows;
     int n, m, ns, cf;
@@ -745,7 +789,7 @@ struct SaParams {
 };
 
 template <int NJF, int NT1, int NT2, int NT3, int NP, class Feed = RingFeed>
-__global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaParams p)
+__global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_kernel(const SaParams p)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
@@ -755,11 +799,24 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
     __shared__ int lmax[4 * C];
     const WgPool pool = wg_pool<NP>(p.rows, p.ns, block);
     if (!pool.on && row0 >= p.rows) return;
+    // the ball's point indices first: the gathers below wait for them, and loads return in
+    // issue order - behind the weight ring's first units they would arrive a ring later
+    int pid[NP];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) pid[g] = p.idx[row0 + 32 * g + pt];
+    __builtin_amdgcn_sched_barrier(0);
     if (pool.on) wg_pool_clear<C>(lmax, pool);
     const long ball = row0 / p.ns;
     const long b = ball / p.m;
     const float *ctr = p.new_xyz + ball * 3;
     int *gmax = reinterpret_cast<int *>(p.out + ball * p.ldo);
+#ifdef FPN_SA_STAMPS      // timing-only build: cycle stamps of one wave into the first output row (wrong results)
+    long long stamp[6];
+    stamp[0] = clock64();
+#define FPN_STAMP(i) stamp[i] = clock64()
+#else
+#define FPN_STAMP(i)
+#endif
 
     Feed feed;
     feed.start(p.ws, lane, feed_ring<Feed>());
@@ -770,9 +827,8 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
         Act in[NP][NJ1];
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
-            const int pid = p.idx[row0 + 32 * g + pt];
-            const float *src = p.xyz + (b * p.n + pid) * 3;
-            const float *f = p.feat + (b * p.n + pid) * (long)p.cf;
+            const float *src = p.xyz + (b * p.n + pid[g]) * 3;
+            const float *f = p.feat + (b * p.n + pid[g]) * (long)p.cf;
 #pragma unroll
             for (int t = 0; t < NJF; ++t)
 #pragma unroll
@@ -801,28 +857,39 @@ __global__ __launch_bounds__(64 * kWaves) void sa_chain_bf16_kernel(const SaPara
         if (pool.on) layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane, p.c3);
         else layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, gmax, feed, lane, p.c3);
     } else {
+        FirstLayer<NT1, 4> first;
+        first.load(p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
+        float x[NP][4];
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
-            const int pid = p.idx[row0 + 32 * g + pt];
-            const float *src = p.xyz + (b * p.n + pid) * 3;
-            float x[4];
+            const float *src = p.xyz + (b * p.n + pid[g]) * 3;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k = 2 * s + h;
                 float v = 0.f;
                 if (k < 3) v = src[k] - ctr[k];
-                else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid) * (long)p.cf + k - 3];
-                x[s] = v;
+                else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid[g]) * (long)p.cf + k - 3];
+                x[g][s] = v;
             }
-            layer_first<NT1, 4>(a1[g], x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
         }
+        FPN_STAMP(1);
+#pragma unroll
+        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
+        FPN_STAMP(2);
         constexpr int U2 = (NT2 / 2) * NT1;
         layer_t<NP, NT1, NT2, 0>(a2, a1, ws, p.sh2, feed, h);
+        FPN_STAMP(3);
         ws += U2 * kUnitVecs;
         if (pool.on) layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane, p.c3);
         else layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, gmax, feed, lane, p.c3);
+        FPN_STAMP(4);
     }
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
+#ifdef FPN_SA_STAMPS
+    stamp[5] = clock64();
+    if (NJF == 0 && blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
+        for (int i = 0; i < 6; ++i) reinterpret_cast<long long *>(p.out)[i] = stamp[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
