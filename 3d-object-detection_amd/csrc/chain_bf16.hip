@@ -643,6 +643,18 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
         p.w10 += f * (128 * 2);
     }
 
+    // Measured with the stamps below (LDS feed, cycles of one wave, MFMA time in brackets): inputs and first
+    // units 1.1 k, conv6 8.3 k [2.0 k], conv7 14.1 k [8.2 k], conv8 4.2 k [2.0 k], conv9 2.5 k [1.0 k], conv10
+    // and store 2.6 k.  conv6 (two units per pair) waits for each pair's shifts from memory; staging all shift
+    // vectors in LDS first took 2 k off conv6 and put 3.7 k onto the start (the wave's first wait for memory
+    // then sits before any MFMA): no gain, not kept.
+#ifdef FPN_TAIL_STAMPS      // timing-only build: cycle stamps of one wave into the first logits (wrong results)
+    long long stamp[7];
+    stamp[0] = clock64();
+#define FPN_TSTAMP(i) stamp[i] = clock64()
+#else
+#define FPN_TSTAMP(i)
+#endif
     Feed feed;
     feed.start(p.ws, lane, feed_ring<Feed>());
     Act pf[1][2];
@@ -655,13 +667,18 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
     const bf16x8 *ws = p.ws;
     Act a6[1][16], a7[1][8], a8[1][4];
     floatx16 a9[1][4];
+    FPN_TSTAMP(1);
     layer_t<1, 2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, feed, h);
+    FPN_TSTAMP(2);
     ws += U6 * kUnitVecs;
     layer_t<1, 16, 8, U6 % kRing>(a7, a6, ws, p.sh7, feed, h);
+    FPN_TSTAMP(3);
     ws += U7 * kUnitVecs;
     layer_t<1, 8, 4, (U6 + U7) % kRing>(a8, a7, ws, p.sh8, feed, h);
+    FPN_TSTAMP(4);
     ws += U8 * kUnitVecs;
     layer_t<1, 4, 4, (U6 + U7 + U8) % kRing>(a9, a8, ws, p.sh9, feed, h);
+    FPN_TSTAMP(5);
 
     // Monte-Carlo dropout before the head (models/FPointNet_Bayes.py:92): bit c of word j
     // of the point's mask keeps channel 32 j + c, kept activations count twice
@@ -691,6 +708,11 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
     s0 += __shfl_xor(s0, 32);
     s1 += __shfl_xor(s1, 32);
     if (h == 0) *reinterpret_cast<float2 *>(p.logits + (row0 + pt) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
+#ifdef FPN_TAIL_STAMPS
+    stamp[6] = clock64();
+    if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
+        for (int i = 0; i < 7; ++i) reinterpret_cast<long long *>(p.logits)[32 + i] = stamp[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
