@@ -813,6 +813,13 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
     const float *ctr = p.new_xyz + ball * 3;
     const float *src = p.xyz + (b * p.n + pid) * 3;
     int *gmax = reinterpret_cast<int *>(p.out + ball * p.ldo);
+#ifdef FPN_SA_STAMPS      // timing-only build: cycle stamps of one wave into the first output row (wrong results)
+    long long stamp[6];
+    stamp[0] = clock64();
+#define FPN_STAMP(i) stamp[i] = clock64()
+#else
+#define FPN_STAMP(i)
+#endif
 
     WChunk ring[4];
     constexpr int NJ1 = NJF > 0 ? NJF + 1 : 2;       // input tiles of layer 1 (unused when NJF = 0)
@@ -855,13 +862,22 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
             else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid) * (long)p.cf + k - 3];
             x[s] = v;
         }
+        FPN_STAMP(1);
         layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
+        FPN_STAMP(2);
         layer_t<NT1, NT2, 0>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
+        FPN_STAMP(3);
         constexpr int P2 = ((NT2 / 2) * NT1) & 1;
         if (pool.on) layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, lmax + pool.local * C, ring, lane, h, p.c3);
         else layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
+        FPN_STAMP(4);
     }
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
+#ifdef FPN_SA_STAMPS
+    stamp[5] = clock64();
+    if (NJF == 0 && blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
+        for (int i = 0; i < 6; ++i) reinterpret_cast<long long *>(p.out)[i] = stamp[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
