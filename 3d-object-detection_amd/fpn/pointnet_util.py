@@ -225,14 +225,15 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
     return True
 
 
-def _mlp_stack(x2d, widths, scope_fmt, bn, pool_rows=0, out=None):
+def _mlp_stack(x2d, widths, scope_fmt, bn, pool_rows=0, out=None, first=0):
     """Shared MLP over the rows of x2d; the pooling over groups of pool_rows rows is
     fused into the last layer when the kernel supports that group size.  `out`, if
-    given, receives the final result (it may be a column slice of a wider buffer)."""
+    given, receives the final result (it may be a column slice of a wider buffer).
+    `first`: index of widths[0] in the scope names (layers before it ran elsewhere)."""
     store = variables.get_default_store()
     fuse_pool = pool_rows and pool_rows % 32 == 0 and (pool_rows <= 128 and 128 % pool_rows == 0 or pool_rows % 128 == 0)
     for i, cout in enumerate(widths):
-        name = variables.scoped(scope_fmt % i)
+        name = variables.scoped(scope_fmt % (first + i))
         w, scale, shift = _layer_params(store, name, x2d.shape[1], cout, bn)
         last = i == len(widths) - 1
         x2d = ops.shared_mlp(x2d, w, scale, shift, relu=True, pool_rows=pool_rows if (last and fuse_pool) else 0,
@@ -329,6 +330,22 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
     xyz2 (B,m,3) sparse, points1 (B,n,c1) or None, points2 (B,m,c2) -> (B,n,mlp[-1])."""
     tf_util._inference_only(is_training)
     with variables.variable_scope(scope):
+        if FUSE_SA and xyz2.shape[1] == 1 and points1 is not None and len(mlp) >= 1:
+            # ONE known point (the level above was a group-all set abstraction): three_nn gives it
+            # weight (1/d)/(1/d) = 1 and the two missing neighbours 1/inf = 0 (tf_interpolate.cpp:60-103),
+            # so every dense point receives points2[:,0,:] exactly and its share of the first layer is one
+            # row per frustum - added as a per-frustum bias, as the v1 seg net does with its global
+            # feature; neither the interpolated tensor nor the concatenation (:218) is made
+            b, n, c1 = points1.shape
+            c2 = points2.shape[2]
+            store = variables.get_default_store()
+            w, scale, shift = _layer_params(store, variables.scoped('conv_0'), c2 + c1, mlp[0], bn)
+            part = ops.shared_mlp(points2[:, 0, :].contiguous(), w[:c2], None, None, relu=False)
+            y = ops.shared_mlp(points1.contiguous().reshape(b * n, c1), w[c2:], scale, shift, relu=True,
+                               group_bias=part, rows_per_group=n)
+            if len(mlp) > 1:
+                y = _mlp_stack(y, mlp[1:], 'conv_%d', bn, first=1)
+            return y.reshape(b, n, y.shape[-1])
         interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous())  # :210-215
         new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated  # :218
         b, n, c = new_points1.shape

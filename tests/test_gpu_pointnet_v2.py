@@ -301,3 +301,38 @@ def test_sa_msg_random_configurations(device):
         np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx, err_msg=str((trial, radii, nsamples, mlps)))
         assert feat.shape == (b, npoint, sum(m[-1] for m in mlps))
         close(feat.cpu().numpy(), wf)
+
+
+@pytest.mark.parametrize("c1,c2,mlp", [(40, 67, [64, 32]), (640, 1027, [128, 128]), (5, 3, [16])])
+def test_fp_module_single_known_point(device, c1, c2, mlp):
+    """Feature propagation from ONE known point (the level above was a group-all set
+    abstraction; models/pointnet_util.py:198-228 with m = 1): the interpolation is an exact
+    broadcast, run here as a per-frustum bias of the first layer.  Against the numpy oracle
+    (which interpolates and concatenates) and against this build's own interpolate-and-
+    concatenate path."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    b, n = 3, 96
+    rng = np.random.RandomState(c1)
+    xyz1 = rng.random_sample((b, n, 3)).astype(np.float32)
+    xyz2 = rng.random_sample((b, 1, 3)).astype(np.float32)
+    p1 = rng.standard_normal((b, n, c1)).astype(np.float32)
+    p2 = rng.standard_normal((b, 1, c2)).astype(np.float32)
+    st = fresh_store(device, seed=9)
+    got = {}
+    for fused in (True, False):
+        old = U.FUSE_SA
+        U.FUSE_SA = fused
+        try:
+            for rnd in (0, 1):
+                with variables.use_store(st):
+                    got[fused] = U.pointnet_fp_module(dev(xyz1, device), dev(xyz2, device), dev(p1, device), dev(p2, device),
+                                                      mlp, False, None, scope='fp1')
+                if fused and rnd == 0:
+                    st.randomize_batch_norm(3)
+        finally:
+            U.FUSE_SA = old
+    want = P.fp_module(xyz1, xyz2, p1, p2, mlp, st.numpy(), "fp1")
+    assert got[True].shape == (b, n, mlp[-1])
+    close(got[True].cpu().numpy(), want)
+    close(got[True].cpu().numpy(), got[False].cpu().numpy(), rtol=1e-5)
