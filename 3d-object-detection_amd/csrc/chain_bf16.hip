@@ -265,7 +265,9 @@ __device__ __forceinline__ floatx16 mfma(const bf16x8 &a, const bf16x8 &b, const
 // accumulators start from zero (the hardware takes the constant, no register clearing).
 // T = true: transposed product (weights are the A operand, result lane = point);
 // T = false: lane = output channel, registers = points.
-template <bool FIRST, bool T, int J, int NP, int NJ>
+// NTILE = 1: the pair's second tile is padding (an odd number of output tiles): its
+// MFMAs are left out.
+template <bool FIRST, bool T, int J, int NTILE = 2, int NP, int NJ>
 __device__ __forceinline__ void unit_mfma(floatx16 (&acc)[2][NP], const WUnit &u, const Act (&in)[NP][NJ])
 {
     const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -274,7 +276,7 @@ __device__ __forceinline__ void unit_mfma(floatx16 (&acc)[2][NP], const WUnit &u
 #pragma unroll
         for (int g = 0; g < NP; ++g)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NTILE; ++t) {
                 const floatx16 c = (FIRST && m == 0) ? z : acc[t][g];
                 acc[t][g] = T ? mfma(u.w[t][m], in[g][J].m[m], c) : mfma(in[g][J].m[m], u.w[t][m], c);
             }
@@ -315,14 +317,18 @@ template <int NP, int NJ, int NT, int R0, class Out, class Feed>
 __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
                                         const float *__restrict__ sh, Feed &feed, int h)
 {
-    static_assert(NJ >= 2 && NT % 2 == 0, "unsupported layer shape");
-    constexpr int U = (NT / 2) * NJ;
+    // an odd NT: the stream still holds whole pairs (the layer's columns zero-padded to a
+    // multiple of 64), the last pair's second tile is neither multiplied nor finished
+    static_assert(NJ >= 2, "unsupported layer shape");
+    constexpr int NPAIR = (NT + 1) / 2;
+    constexpr int U = NPAIR * NJ;
     floatx16 acc[2][2][NP];
     TileConst csh[2];
     static_for<0, U>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
         constexpr int slot = (R0 + S) % kRing;
-        unit_mfma<j == 0, true, j>(acc[set], feed.template cur<slot>(), in);
+        constexpr int ntile = 2 * tp + 1 < NT ? 2 : 1;
+        unit_mfma<j == 0, true, j, ntile>(acc[set], feed.template cur<slot>(), in);
         feed.template advance<slot>(ws + (size_t)S * kUnitVecs);
         if constexpr (tp > 0 && j < 2) {
 #pragma unroll
@@ -330,16 +336,17 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
         }
         if constexpr (j == NJ - 1) {          // shifts of this pair, wanted one unit from now
             load_const(csh[0], sh, 32 * (2 * tp) + 4 * h);
-            load_const(csh[1], sh, 32 * (2 * tp + 1) + 4 * h);
+            if constexpr (ntile == 2) load_const(csh[1], sh, 32 * (2 * tp + 1) + 4 * h);
         }
-        sched_unit<Feed::kCoop, 4 * NP, j == NJ - 1 ? 12 : 4, (tp > 0 && j < 2) ? (48 * NP + 4 * NP - 1) / (4 * NP) : 1>();
+        sched_unit<Feed::kCoop, 2 * ntile * NP, j == NJ - 1 ? 4 + 4 * ntile : 4,
+                   (tp > 0 && j < 2) ? (48 * NP + 2 * ntile * NP - 1) / (2 * ntile * NP) : 1>();
         feed.template sync<slot>();
     });
-    constexpr int last = (NT / 2 - 1) & 1;
+    constexpr int last = (NPAIR - 1) & 1;
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
-        finish(out[g][NT - 2], acc[last][0][g], csh[0]);
-        finish(out[g][NT - 1], acc[last][1][g], csh[1]);
+        finish(out[g][2 * NPAIR - 2], acc[last][0][g], csh[0]);
+        if constexpr (NT % 2 == 0) finish(out[g][NT - 1], acc[last][1][g], csh[1]);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -432,7 +439,9 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
                                           const float *__restrict__ sh, int *gmax, Feed &feed, unsigned lane,
                                           int cvalid = 32 * NT)
 {
-    static_assert(NJ >= 2 && NT % 4 == 0 && (2 * NJ) % kRing == 0, "unsupported layer shape");
+    // (a trip of the loop below takes 2 NJ units: with more than one trip the ring and feed
+    // phases must come round)
+    static_assert(NJ >= 2 && NT % 4 == 0 && (NT == 4 || (2 * NJ) % kRing == 0), "unsupported layer shape");
     const int c = lane & 31;
     floatx16 acc[2][2][NP];
     const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 #pragma unroll
         for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
         FPN_STAMP(2);
-        constexpr int U2 = (NT2 / 2) * NT1;
+        constexpr int U2 = ((NT2 + 1) / 2) * NT1;
         layer_t<NP, NT1, NT2, 0>(a2, a1, ws, p.sh2, feed, h);
         FPN_STAMP(3);
         ws += U2 * kUnitVecs;
@@ -1247,8 +1256,9 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
     FPN_REQUIRE(ns % 32 == 0, "sa_chain_bf16: samples per ball (%d) must be a multiple of 32", ns);
     FPN_REQUIRE(c3_valid >= 64 && c3_valid % 64 == 0 && c3_valid <= c3 && ldo >= c3_valid,
                 "sa_chain_bf16: bad output width %d (c3 %d, ld %d)", c3_valid, c3, ldo);
-    // (the bf16 weight streams pair output tiles: every width a multiple of 64)
-    if (c2 % 64 != 0 || !fpn_sa_chain_supported(cf, c1, c2, c3))
+    // (the bf16 weight streams pair output tiles: widths are multiples of 64, except the middle layer of the
+    // 64-96-128 stack, whose stream holds the layer padded to 128 columns and the last layer with 96 rows)
+    if ((c2 % 64 != 0 && !(cf < 32 && c1 == 64 && c2 == 96 && c3 == 128)) || !fpn_sa_chain_supported(cf, c1, c2, c3))
         return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
     if (b == 0) return FPN_OK;
     FPN_REQUIRE(xyz && new_xyz && idx && wstream && consts && out && (cf == 0 || feat), "sa_chain_bf16: null pointer");
@@ -1267,6 +1277,7 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
     p.out = out; p.ldo = ldo; p.c3 = c3_valid;
     hipStream_t st = as_stream(stream);
     if (njf == 0 && t2 == 2) return launch_sa<0, 2, 2, 4>(p, st);
+    if (njf == 0 && t2 == 3) return launch_sa<0, 2, 3, 4>(p, st);
     if (njf == 0) return launch_sa<0, 2, 4, 4>(p, st);
     if (njf == 10 && t1 == 2) return launch_sa<10, 2, 2, 4>(p, st);
     if (njf == 10) return launch_sa<10, 4, 4, 8>(p, st);

@@ -130,10 +130,10 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     pad = None
     for mid in (32, 64):
         cand = (_round_up(widths[0], 64), _round_up(widths[1], mid), _round_up(widths[2], 128))
-        if SA_PRECISION != "bf16" or mid == 64:        # (the bf16 streams pair output tiles: multiples of 64)
-            if _lib.load().fpn_sa_chain_supported(cf, *cand):
-                pad = cand
-                break
+        if _lib.load().fpn_sa_chain_supported(cf, *cand) and \
+                (SA_PRECISION != "bf16" or mid == 64 or (cf < 32 and cand == (64, 96, 128))):
+            pad = cand
+            break
     if pad is None:
         # the variables are created by the per-layer path
         return None
@@ -173,7 +173,13 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
             stream = ops.chain_stream_bf16([(w1p, s1p), (w2p, s2p), (w3p, s3p)])
             tensors = [h1p, h2p, h3p]
         else:
-            stream = ops.chain_stream_bf16([(w2p, s2p), (w3p, s3p)])
+            if pad[1] % 64:
+                # the stream pairs output tiles: the middle layer goes in with its columns zero-padded to a
+                # multiple of 64 (the kernel leaves the padding tile out), the last layer with pad[1] rows
+                w2s, s2s, _ = padded(*params[1], pad[0], _round_up(pad[1], 64))
+                stream = ops.chain_stream_bf16([(w2s, s2s), (w3p, s3p)])
+            else:
+                stream = ops.chain_stream_bf16([(w2p, s2p), (w3p, s3p)])
             tensors = [w1k.contiguous(), s1p, h1p, h2p, h3p]
         plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "pad": pad,
                 "stream": stream}

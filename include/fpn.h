@@ -444,7 +444,8 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
                           float *feat_max, int ldg, void *stream);
 /* Shapes and padding rules of fpn_sa_chain_f32; c3_valid % 64 == 0.
  *   cf < 32 : stream: layer 2, layer 3; consts {w1 (3+cf,c1) fp32, scale1, shift1,
- *             shift2, shift3};
+ *             shift2, shift3}; with c2 = 96 (c1 = 64, c3 = 128) the stream holds layer 2
+ *             packed as (64,128) - columns 96..127 zero - and layer 3 as (96,128);
  *   cf >= 32: stream: layer 1 (rows [features, dx,dy,dz, 29 zero rows]), layer 2,
  *             layer 3; consts {shift1, shift2, shift3}. */
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,

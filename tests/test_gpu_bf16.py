@@ -132,6 +132,7 @@ def test_bf16_set_abstraction_within_stated_bound(device):
         ("msg", xyz_small, rng.standard_normal((b, 128, 320)).astype(np.float32),
          (32, [0.4, 0.8, 1.6], [64, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]])),
         ("ssg", xyz_big, None, (64, 0.2, 64, [64, 64, 128])),
+        ("ssg", xyz_big, None, (64, 0.3, 32, [64, 96, 128])),       # three-tile middle layer, one point group per wave
         ("ssg", xyz_small, rng.standard_normal((b, 128, 128)).astype(np.float32), (32, 0.4, 64, [128, 128, 256])),
     ]
     for kind, xyz, pts, args in cases:
