@@ -74,7 +74,9 @@ _GROUP_ALL_CONSTANTS = {}
 
 def _group_all_constants(b, n, device):
     """The centroid (0,0,0) and the index table 0..n-1 of sample_and_group_all: the same
-    for every call of a shape, so they are made once (read-only by convention)."""
+    for every call of a shape, so they are made once.  The index table is handed out as
+    an expanded (stride-0) view, which torch refuses to write in place; the caller gets its
+    own copy of the centroid."""
     key = (b, n, device)
     hit = _GROUP_ALL_CONSTANTS.get(key)
     if hit is None:
@@ -91,6 +93,7 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     no translation."""
     b, n, _ = xyz.shape
     new_xyz, idx = _group_all_constants(b, n, xyz.device)
+    new_xyz = new_xyz.clone()
     grouped_xyz = xyz.reshape(b, 1, n, 3)
     if points is not None:
         new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
