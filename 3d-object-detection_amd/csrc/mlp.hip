@@ -342,6 +342,189 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
 }
 
 // ---------------------------------------------------------------------------
+// The same layer on the bf16 matrix instruction (v_mfma_f32_32x32x16_bf16, fp32
+// accumulation) for the wide per-point layers of the PointNet++ nets whose inputs are
+// features, not coordinates: x is converted to bf16 while it is staged, the weights
+// arrive transposed and converted (fpn_mlp_pack_bf16: wt (cout, cin rounded up to 64),
+// zero beyond cin), so that both LDS images hold a row's / a column's K values
+// contiguously and an operand fragment (8 consecutive k of one row or column: lane
+// (i = lane&31, g = lane>>5) supplies k = 16 s + 8 g .. + 7) is one 16-byte read.  Rows
+// of both images are 72 bf16 = 144 bytes apart: 16 consecutive rows then start in 16
+// different groups of four banks.  A workgroup owns 128 rows x 128 columns (2 x 2 waves,
+// 2 x 2 tiles each) and walks K 64 at a time through double-buffered images, one barrier
+// per step.  Epilogue as shared_mlp_kernel (group bias, scale, shift, ReLU, max over
+// groups of rows), all in fp32.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kHK = 64;        // K per LDS tile
+constexpr int kHS = kHK + 8;   // image row stride (bf16)
+
+__global__ void mlp_pack_bf16_kernel(int cin, int cout, int ldw, const float *__restrict__ w, __bf16 *__restrict__ wt)
+{
+    const long total = (long)cout * ldw;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(e / ldw), k = (int)(e % ldw);
+        wt[e] = (__bf16)(k < cin ? w[(long)k * cout + col] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_kernel(const MlpParams p)
+{
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[2][BM * kHS];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][BN * kHS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ncb = (p.cout + BN - 1) / BN;
+    const long row0 = (long)(blockIdx.x / ncb) * BM;
+    const int col0 = (int)(blockIdx.x % ncb) * BN;
+    const __bf16 *wt = reinterpret_cast<const __bf16 *>(p.w);
+    const int ldw = (p.cin + kHK - 1) / kHK * kHK;
+    const int ktiles = ldw / kHK;
+    const bool xvec = (p.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+
+    float4 xr[8];
+    bf16x8 wr[4];
+    auto load_tile = [&](int t) {
+        const int k0 = t * kHK;
+        const int kq = tid & 15, r = tid >> 4;
+        const int k = k0 + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long row = row0 + r + 16 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.rows) {
+                const float *src = p.x + row * p.ldx + k;
+                if (xvec && k + 3 < p.cin) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    if (k + 0 < p.cin) v.x = src[0];
+                    if (k + 1 < p.cin) v.y = src[1];
+                    if (k + 2 < p.cin) v.z = src[2];
+                    if (k + 3 < p.cin) v.w = src[3];
+                }
+            }
+            xr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + kMlpThreads * i, col = col0 + (id >> 3), kv = id & 7;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            if (col < p.cout) v = *reinterpret_cast<const bf16x8 *>(wt + (long)col * ldw + k0 + 8 * kv);
+            wr[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        const int kq = tid & 15, r = tid >> 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bf16x4 v;
+            v[0] = (__bf16)xr[i].x; v[1] = (__bf16)xr[i].y; v[2] = (__bf16)xr[i].z; v[3] = (__bf16)xr[i].w;
+            *reinterpret_cast<bf16x4 *>(&Xs[buf][(r + 16 * i) * kHS + 4 * kq]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + kMlpThreads * i;
+            *reinterpret_cast<bf16x8 *>(&Ws[buf][(id >> 3) * kHS + 8 * (id & 7)]) = wr[i];
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ktiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ktiles) load_tile(t + 1);
+        const __bf16 *xs = &Xs[buf][(wm * 64 + l31) * kHS + 8 * half];
+        const __bf16 *ws = &Ws[buf][(wn * 64 + l31) * kHS + 8 * half];
+#pragma unroll
+        for (int s = 0; s < kHK / 16; ++s) {
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = *reinterpret_cast<const bf16x8 *>(xs + a * 32 * kHS + 16 * s);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bv[b] = *reinterpret_cast<const bf16x8 *>(ws + b * 32 * kHS + 16 * s);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (t + 1 < ktiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (as shared_mlp_kernel) ------------------------------------------
+    float *red = reinterpret_cast<float *>(Xs[0]);  // (BM/32, BN) tile maxima; the K loop ended on a barrier
+    const bool pooled = p.pool_rows > 0;
+    const bool gb_tile_uniform = p.group_bias && (p.rows_per_group % 32 == 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + (wn * 2 + b) * 32 + l31;
+        const bool colok = col < p.cout;
+        const float sc = (colok && p.scale) ? p.scale[col] : 1.f;
+        const float sh = (colok && p.shift) ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int trow = (wm * 2 + a) * 32;
+            float gbu = 0.f;
+            if (gb_tile_uniform && colok && row0 + trow < p.rows)
+                gbu = p.group_bias[((row0 + trow) / p.rows_per_group) * p.cout + col];
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + trow + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float v = acc[a][b][r];
+                if (p.group_bias) {
+                    if (gb_tile_uniform) v += gbu;
+                    else if (colok && row < p.rows) v += p.group_bias[(row / p.rows_per_group) * p.cout + col];
+                }
+                v = v * sc + sh;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (pooled) m = fmaxf(m, v);
+                else if (colok && row < p.rows) p.y[row * p.ldy + col] = v;
+            }
+            if (pooled) {
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (half == 0) red[(wm * 2 + a) * BN + (wn * 2 + b) * 32 + l31] = m;
+            }
+        }
+    }
+    if (!pooled) return;
+    __syncthreads();
+    const int col = col0 + tid;
+    if (tid < BN && col < p.cout) {
+        if (p.pool_rows <= BM) {
+            const int tiles_per_group = p.pool_rows / 32;
+            for (int g = 0; g < BM / p.pool_rows; ++g) {
+                const long grow = row0 + (long)g * p.pool_rows;
+                if (grow >= p.rows) break;
+                float m = red[g * tiles_per_group * BN + tid];
+                for (int u = 1; u < tiles_per_group; ++u) m = fmaxf(m, red[(g * tiles_per_group + u) * BN + tid]);
+                p.y[(grow / p.pool_rows) * p.ldy + col] = m;
+            }
+        } else {
+            float m = red[tid];
+            for (int u = 1; u < BM / 32; ++u) m = fmaxf(m, red[u * BN + tid]);
+            p.partial[(row0 / BM) * p.cout + col] = m;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Few rows (fully connected layers: one row per frustum; the small feature-propagation
 // and group-all layers of the PointNet++ variant): 128-row tiles would leave most of
 // the chip idle and a K loop through LDS with a barrier per step leaves each
@@ -685,6 +868,49 @@ int fpn_shared_mlp_f32(long rows, int cin, int cout, const float *x, int ldx, co
     p.relu = relu; p.pool_rows = pool_rows; p.y = y; p.ldy = ldy;
     p.partial = static_cast<float *>(workspace);
     return launch_mlp<kPlain>(p, as_stream(stream));
+}
+
+int fpn_mlp_pack_bf16(int cin, int cout, const float *w, void *wt, void *stream)
+{
+    FPN_REQUIRE(cin >= 1 && cout >= 1, "mlp_pack_bf16: bad size cin=%d cout=%d", cin, cout);
+    FPN_REQUIRE(w && wt, "mlp_pack_bf16: null pointer");
+    const int ldw = (cin + kHK - 1) / kHK * kHK;
+    const long total = (long)cout * ldw;
+    hipLaunchKernelGGL(mlp_pack_bf16_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       as_stream(stream), cin, cout, ldw, w, static_cast<__bf16 *>(wt));
+    return check_launch("fpn_mlp_pack_bf16");
+}
+
+int fpn_shared_mlp_bf16(long rows, int cin, int cout, const float *x, int ldx, const void *wt,
+                        const float *scale, const float *shift, const float *group_bias,
+                        int rows_per_group, int relu, int pool_rows, float *y, int ldy, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    int rc = check_common("shared_mlp_bf16", rows, cin, cout, x, ldx, static_cast<const float *>(wt), pool_rows, y, ldy,
+                          workspace, workspace_bytes);
+    if (rc != FPN_OK) return rc;
+    if (group_bias) FPN_REQUIRE(rows_per_group >= 1, "shared_mlp_bf16: group_bias needs rows_per_group >= 1");
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(wt) & 15) == 0, "shared_mlp_bf16: wt must be 16-byte aligned");
+    if (rows == 0) return FPN_OK;
+    MlpParams p{};
+    p.rows = rows; p.cin = cin; p.cout = cout; p.x = x; p.ldx = ldx; p.w = static_cast<const float *>(wt);
+    p.scale = scale; p.shift = shift; p.group_bias = group_bias;
+    p.rows_per_group = group_bias ? rows_per_group : 1;
+    p.relu = relu; p.pool_rows = pool_rows; p.y = y; p.ldy = ldy;
+    p.partial = static_cast<float *>(workspace);
+    hipStream_t st = as_stream(stream);
+    const long nblk = ((rows + kBM - 1) / kBM) * ((cout + 127) / 128);
+    FPN_REQUIRE(nblk <= INT32_MAX, "shared_mlp_bf16: grid too large");
+    hipLaunchKernelGGL(shared_mlp_bf16_kernel, dim3((unsigned)nblk), dim3(kMlpThreads), 0, st, p);
+    rc = check_launch("fpn_shared_mlp_bf16");
+    if (rc != FPN_OK) return rc;
+    if (pool_rows > kBM) {
+        const long groups = rows / pool_rows;
+        const int blocks = (int)std::min<long>((groups * cout + 255) / 256, 65536);
+        hipLaunchKernelGGL(pool_finish_kernel, dim3(blocks), dim3(256), 0, st, groups, cout, pool_rows / kBM, p.partial, y, ldy);
+        rc = check_launch("fpn_shared_mlp_bf16(pool)");
+    }
+    return rc;
 }
 
 int fpn_shared_mlp_static_f32(long rows, int cin, int cout, const float *x, int ldx, const float *w,

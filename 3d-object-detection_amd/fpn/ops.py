@@ -42,9 +42,24 @@ def _check_layer_operands(x, w, cin, cout, scale, shift, group_bias, groups, ext
     _lib.same_device(x, w, scale, shift, group_bias, *[t for _, t, _ in extra])
 
 
+def pack_mlp_bf16(w):
+    """w (cin,cout) float32 -> the layer's weights as fpn_shared_mlp_bf16 reads them:
+    (cout, cin rounded up to 64) bf16, transposed, zero beyond cin (fpn_mlp_pack_bf16)."""
+    _lib.require_device_tensor("w", w, torch.float32, 2)
+    if not w.is_contiguous():
+        raise ValueError("w must be a dense (cin,cout) matrix")
+    cin, cout = w.shape
+    wt = torch.empty((cout, (cin + 63) // 64 * 64), dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().fpn_mlp_pack_bf16(cin, cout, _lib.ptr(w), _lib.ptr(wt), _lib.stream_of(w)))
+    return wt
+
+
 def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=None,
-               rows_per_group=0, out=None, cin=None):
-    """One fused layer through fpn_shared_mlp_f32.
+               rows_per_group=0, out=None, cin=None, wt_bf16=None):
+    """One fused layer through fpn_shared_mlp_f32 - or, with wt_bf16 = pack_mlp_bf16(w),
+    through fpn_shared_mlp_bf16 (bf16 operands, fp32 accumulation and epilogue; for layers
+    whose inputs are features, not coordinates).
 
     x (rows, ldx) float32 with the layer's inputs in columns [0,cin) (cin defaults
     to w.shape[0]); w (cin,cout); scale/shift (cout,) or None; group_bias
@@ -76,6 +91,20 @@ def shared_mlp(x, w, scale=None, shift=None, relu=True, pool_rows=0, group_bias=
     if ws_bytes:
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     obs = launch_observer
+    if wt_bf16 is not None:
+        if wt_bf16.dtype != torch.bfloat16 or tuple(wt_bf16.shape) != (cout, (cin + 63) // 64 * 64) \
+                or not wt_bf16.is_contiguous() or wt_bf16.device != x.device:
+            raise ValueError("wt_bf16 must be pack_mlp_bf16(w): a dense bfloat16 (%d, %d) tensor on %s"
+                             % (cout, (cin + 63) // 64 * 64, x.device))
+        tok = obs.begin("shared_mlp_bf16", rows, cin, cout) if obs is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fpn_shared_mlp_bf16(rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(wt_bf16), _lib.ptr(scale),
+                                               _lib.ptr(shift), _lib.ptr(group_bias), int(rows_per_group),
+                                               int(bool(relu)), int(pool_rows), _lib.ptr(out), ldy,
+                                               _lib.ptr(ws), ws_bytes, _lib.stream_of(x)))
+        if obs is not None:
+            obs.end(tok)
+        return out
     tok = obs.begin(mlp_kernel_name(cout, rows, cin, pool_rows), rows, cin, cout) if obs is not None else None
     with torch.cuda.device(x.device):
         _lib.check(lib.fpn_shared_mlp_f32(rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(w), _lib.ptr(scale),

@@ -234,19 +234,41 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
     return True
 
 
-def _mlp_stack(x2d, widths, scope_fmt, bn, pool_rows=0, out=None, first=0):
+# Rows from which a per-layer call takes the bf16 kernel under SA_PRECISION = "bf16".  Zero:
+# the operand type of a layer does not depend on the batch size, so a frustum's results do
+# not either (with few rows the fp32 few-row forms would be some microseconds faster).
+BF16_LAYER_MIN_ROWS = 0
+
+
+def _packed_bf16(store, name, w):
+    """pack_mlp_bf16 of a layer's weights, cached on the store until its variables change
+    (`name`: the cache key - the layer's scope, plus a suffix for a row slice)."""
+    cache = store.__dict__.setdefault("_mlp_bf16_cache", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != store.version:
+        hit = (store.version, ops.pack_mlp_bf16(w.contiguous()))
+        cache[name] = hit
+    return hit[1]
+
+
+def _mlp_stack(x2d, widths, scope_fmt, bn, pool_rows=0, out=None, first=0, coords_in_first=False):
     """Shared MLP over the rows of x2d; the pooling over groups of pool_rows rows is
     fused into the last layer when the kernel supports that group size.  `out`, if
     given, receives the final result (it may be a column slice of a wider buffer).
-    `first`: index of widths[0] in the scope names (layers before it ran elsewhere)."""
+    `first`: index of widths[0] in the scope names (layers before it ran elsewhere).
+    Under SA_PRECISION = "bf16" layers with many rows run on bf16 operands, except one whose
+    input holds coordinates (`coords_in_first`: the first layer's does)."""
     store = variables.get_default_store()
     fuse_pool = pool_rows and pool_rows % 32 == 0 and (pool_rows <= 128 and 128 % pool_rows == 0 or pool_rows % 128 == 0)
     for i, cout in enumerate(widths):
         name = variables.scoped(scope_fmt % (first + i))
         w, scale, shift = _layer_params(store, name, x2d.shape[1], cout, bn)
         last = i == len(widths) - 1
+        wt = None
+        if SA_PRECISION == "bf16" and x2d.shape[0] >= BF16_LAYER_MIN_ROWS and not (i == 0 and coords_in_first):
+            wt = _packed_bf16(store, name, w)
         x2d = ops.shared_mlp(x2d, w, scale, shift, relu=True, pool_rows=pool_rows if (last and fuse_pool) else 0,
-                             out=out if (last and (fuse_pool or not pool_rows)) else None)
+                             out=out if (last and (fuse_pool or not pool_rows)) else None, wt_bf16=wt)
     if pool_rows and not fuse_pool:
         x2d = ops.max_pool_rows(x2d, pool_rows, out=out)
     return x2d
@@ -277,10 +299,11 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                                                                      knn, use_xyz, sampled=sampled)
         b, m, ns, c = new_points.shape
         x2d = new_points.contiguous().reshape(b * m * ns, c)
+        has_xyz = points is None or use_xyz       # the first layer's input holds coordinates
         if pooling == 'max':
-            pooled = _mlp_stack(x2d, mlp, 'conv%d', bn, pool_rows=ns)                    # :116-126
+            pooled = _mlp_stack(x2d, mlp, 'conv%d', bn, pool_rows=ns, coords_in_first=has_xyz)   # :116-126
         else:
-            feat = _mlp_stack(x2d, mlp, 'conv%d', bn)
+            feat = _mlp_stack(x2d, mlp, 'conv%d', bn, coords_in_first=has_xyz)
             feat = feat.reshape(b, m, ns, feat.shape[-1])
             if pooling == 'avg':
                 pooled = feat.mean(dim=2)
@@ -329,7 +352,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
                 grouped = group_concat(xyz, new_xyz, None, idx)
             x2d = grouped.reshape(b * m * nsample, grouped.shape[-1])
             _mlp_stack(x2d, mlp_list[i], 'conv%d_' % i + '%d', bn, pool_rows=nsample,
-                       out=out[:, col:col + w_i])                                                  # :187-194
+                       out=out[:, col:col + w_i], coords_in_first=points is None or use_xyz)       # :187-194
             col += w_i
         return new_xyz, out.reshape(b, m, width)
 
@@ -350,8 +373,11 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             store = variables.get_default_store()
             w, scale, shift = _layer_params(store, variables.scoped('conv_0'), c2 + c1, mlp[0], bn)
             part = ops.shared_mlp(points2[:, 0, :].contiguous(), w[:c2], None, None, relu=False)
+            wt = None
+            if SA_PRECISION == "bf16" and b * n >= BF16_LAYER_MIN_ROWS:
+                wt = _packed_bf16(store, variables.scoped('conv_0') + "#own", w[c2:])
             y = ops.shared_mlp(points1.contiguous().reshape(b * n, c1), w[c2:], scale, shift, relu=True,
-                               group_bias=part, rows_per_group=n)
+                               group_bias=part, rows_per_group=n, wt_bf16=wt)
             if len(mlp) > 1:
                 y = _mlp_stack(y, mlp[1:], 'conv_%d', bn, first=1)
             return y.reshape(b, n, y.shape[-1])

@@ -176,6 +176,23 @@ int fpn_shared_mlp_f32(long rows, int cin, int cout, const float *x, int ldx, co
 size_t fpn_shared_mlp_workspace_bytes(long rows, int cout, int pool_rows);
 
 /*
+ * fpn_shared_mlp_f32 on the bf16 matrix instruction (fp32 accumulation, fp32 epilogue):
+ * the same layer - tf_util.conv2d / conv1d of models/tf_util.py:120-185 as the
+ * PointNet++ modules use it (models/pointnet_util.py:116-126,142-150,222-226) - for wide
+ * per-point layers whose inputs are FEATURES (x is rounded to bf16 on the way in:
+ * coordinates in metres would lose their decimetres).  Results differ from the fp32
+ * entry point by bf16 rounding of both operands (2^-9 relative each).
+ *   wt: the weights transposed and converted by fpn_mlp_pack_bf16: (cout, ldw) bf16,
+ *   ldw = cin rounded up to a multiple of 64, zeros beyond cin; 16-byte aligned.
+ *   Everything else as fpn_shared_mlp_f32.
+ */
+int fpn_mlp_pack_bf16(int cin, int cout, const float *w, void *wt, void *stream);
+int fpn_shared_mlp_bf16(long rows, int cin, int cout, const float *x, int ldx, const void *wt,
+                        const float *scale, const float *shift, const float *group_bias,
+                        int rows_per_group, int relu, int pool_rows, float *y, int ldy,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * fpn_shared_mlp_f32 for callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments
  * minus the workspace, same kernels, same results bit for bit.  The partial maxima of a

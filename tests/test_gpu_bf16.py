@@ -272,3 +272,50 @@ def test_bf16_weight_feeds_agree_bit_for_bit(device, monkeypatch, B, N, dropout)
         got[feed] = {k: ep[k].clone() for k in ("mask_logits", "box_output", "stage1_center")}
     for k in got["ring"]:
         assert torch.equal(got["ring"][k], got["lds"][k]), k
+
+
+@pytest.mark.parametrize("rows,cin,cout,pool,gb", [
+    (300, 67, 59, 0, 0), (4096, 448, 128, 0, 0), (1024, 643, 200, 32, 0), (2048, 256, 1024, 64, 0),
+    (1536, 128, 256, 128, 0), (2048, 640, 128, 0, 256), (4096, 256, 512, 512, 0), (640, 130, 128, 0, 5),
+])
+def test_bf16_tiled_layer(device, rows, cin, cout, pool, gb):
+    """fpn_shared_mlp_bf16 (the per-layer kernel on bf16 operands): on small-integer data -
+    exact in bf16, sums exact in fp32 - it must equal the fp32 kernel bit for bit, for ragged
+    rows, K and column counts off the tile sizes, every pooling form and the group bias; on
+    random data it stays within the bf16 bound of the float64 product of the rounded operands."""
+    from fpn import ops
+    rng = np.random.RandomState(rows + cin)
+    ldx = cin + 3
+    for kind in ("int", "real"):
+        if kind == "int":
+            x = rng.randint(-3, 4, (rows, ldx)).astype(np.float32)
+            w = rng.randint(-2, 3, (cin, cout)).astype(np.float32)
+            scale = rng.randint(1, 3, cout).astype(np.float32)
+            shift = rng.randint(-4, 5, cout).astype(np.float32)
+        else:
+            x = rng.standard_normal((rows, ldx)).astype(np.float32)
+            w = (rng.standard_normal((cin, cout)) * cin ** -0.5).astype(np.float32)
+            scale = (rng.random_sample(cout) + 0.5).astype(np.float32)
+            shift = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        bias = None
+        if gb:
+            groups = -(-rows // gb)
+            bias = (rng.randint(-3, 4, (groups, cout)) if kind == "int" else rng.standard_normal((groups, cout))).astype(np.float32)
+        xd, wd = dev(x, device), dev(w, device)
+        kw = dict(relu=True, pool_rows=pool, group_bias=None if bias is None else dev(bias, device), rows_per_group=gb)
+        want32 = ops.shared_mlp(xd[:, :cin], wd, dev(scale, device), dev(shift, device), **kw)
+        got = ops.shared_mlp(xd[:, :cin], wd, dev(scale, device), dev(shift, device), wt_bf16=ops.pack_mlp_bf16(wd), **kw)
+        assert got.shape == want32.shape
+        if kind == "int":
+            assert torch.equal(got, want32)
+        else:
+            xb = torch.from_numpy(x[:, :cin]).bfloat16().double().numpy()
+            wb = torch.from_numpy(w).bfloat16().double().numpy()
+            acc = xb @ wb
+            if bias is not None:
+                acc = acc + np.repeat(bias.astype(np.float64), gb, axis=0)[:rows]
+            v = np.maximum(acc * scale + shift, 0)
+            if pool:
+                v = v.reshape(rows // pool, pool, cout).max(axis=1)
+            assert scaled_err(got.cpu().numpy(), v) <= 1e-4          # fp32 accumulation of exact bf16 products
+            assert scaled_err(got.cpu().numpy(), want32.cpu().numpy()) <= BF16_RTOL
