@@ -29,7 +29,8 @@ def main():
     dev = torch.device("cuda:0")
     if len(sys.argv) > 1 and sys.argv[1] == "bf16":
         pointnet_util.SA_PRECISION = "bf16"
-    pc_np, oh_np = synthetic.make_frustums_range(0, 256, 2048, 4, seed=0)
+    frustums = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    pc_np, oh_np = synthetic.make_frustums_range(0, frustums, 2048, 4, seed=0)
     pc, oh = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
     st = variables.VariableStore(dev, seed=1)
     with variables.use_store(st):
