@@ -290,6 +290,24 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             if _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx.contiguous(), mlp,
                          'conv%d', bn, pooled, xyz_first=True):
                 return new_xyz, pooled.reshape(xyz.shape[0], npoint, pooled.shape[-1]), idx
+        if group_all and SA_PRECISION == "bf16" and FUSE_SA and points is not None and use_xyz \
+                and pooling == 'max' and len(mlp) >= 2:
+            # group-all in bf16: the first layer's input is [xyz | features] (:77); the three coordinate
+            # columns go through the fp32 kernel (K = 3), the features through the bf16 kernel with that
+            # product as a per-row bias - the concatenated tensor is not made
+            b, n, _ = xyz.shape
+            cfeat = points.shape[2]
+            store = variables.get_default_store()
+            name0 = variables.scoped('conv0')
+            w, scale, shift = _layer_params(store, name0, 3 + cfeat, mlp[0], bn)
+            new_xyz, idx = _group_all_constants(b, n, xyz.device)
+            part = ops.shared_mlp(xyz.contiguous().reshape(b * n, 3), w[:3], None, None, relu=False)
+            y = ops.shared_mlp(points.contiguous().reshape(b * n, cfeat), w[3:], scale, shift, relu=True, group_bias=part,
+                               rows_per_group=1, wt_bf16=_packed_bf16(store, name0 + "#features", w[3:]))
+            pooled = _mlp_stack(y, mlp[1:], 'conv%d', bn, pool_rows=n, first=1)
+            if mlp2 is not None:
+                pooled = _mlp_stack(pooled, mlp2, 'conv_post_%d', bn)
+            return new_xyz.clone(), pooled.reshape(b, 1, pooled.shape[-1]), idx
         if group_all:
             nsample = xyz.shape[1]
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
