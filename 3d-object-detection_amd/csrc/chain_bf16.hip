@@ -48,6 +48,7 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef short shortx2 __attribute__((ext_vector_type(2)));
 typedef short shortx8 __attribute__((ext_vector_type(8)));
@@ -932,6 +933,7 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 struct FpHeadParams {
     long rows;
     int cb;
+    int xa_bf16;            // xa holds bf16 values (fpn_three_nn_interpolate_bf16), else float
     const float *xa, *xb;
     const bf16x8 *ws;
     const float *sh1, *sh2, *sh3;
@@ -954,17 +956,30 @@ __global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadP
     floatx16 a3[NP][4];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
-        const float *xa = p.xa + (row0 + 32 * g + pt) * (32 * NJA);
+        if (p.xa_bf16) {        // (workgroup-uniform) the rows are bf16 already: half the bytes, the same values
+            const bf16x4 *xa = reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(p.xa) +
+                                                                 (row0 + 32 * g + pt) * (32 * NJA));
 #pragma unroll
-        for (int t = 0; t < NJA; ++t)
+            for (int t = 0; t < NJA; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4 *>(xa + 32 * t + 8 * q + 4 * h);
-                in[g][t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
-                in[g][t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
-                in[g][t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
-                in[g][t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x4 v = xa[8 * t + 2 * q + h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) in[g][t].m[q >> 1][4 * (q & 1) + e] = v[e];
+                }
+        } else {
+            const float *xa = p.xa + (row0 + 32 * g + pt) * (32 * NJA);
+#pragma unroll
+            for (int t = 0; t < NJA; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xa + 32 * t + 8 * q + 4 * h);
+                    in[g][t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
+                    in[g][t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
+                    in[g][t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
+                    in[g][t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
+                }
+        }
         const float *xb = p.xb + (row0 + 32 * g + pt) * (long)p.cb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1226,9 +1241,10 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
     return check_launch("fpn_v1_obj_chain_bf16");
 }
 
-int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const float *xb, const void *wstream,
-                           const float *const *consts, float *logits, void *stream)
+static int fp_head_chain_bf16(long rows, int ca, int cb, const void *xa_any, int xa_bf16, const float *xb,
+                              const void *wstream, const float *const *consts, float *logits, void *stream)
 {
+    const float *xa = static_cast<const float *>(xa_any);
     FPN_REQUIRE(rows >= 0 && rows % 32 == 0, "fp_head_chain_bf16: rows (%ld) must be a multiple of 32", rows);
     FPN_REQUIRE(ca == 128, "fp_head_chain_bf16: %d interpolated channels, a kernel exists for 128", ca);
     FPN_REQUIRE(cb >= 0 && cb <= 32, "fp_head_chain_bf16: at most 32 own channels per point (%d)", cb);
@@ -1237,7 +1253,7 @@ int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const flo
     for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "fp_head_chain_bf16: constant %d is null", i);
     FPN_REQUIRE((reinterpret_cast<uintptr_t>(xa) & 15) == 0, "fp_head_chain_bf16: xa must be 16-byte aligned");
     FpHeadParams p{};
-    p.rows = rows; p.cb = cb; p.xa = xa; p.xb = cb ? xb : xa;
+    p.rows = rows; p.cb = cb; p.xa_bf16 = xa_bf16; p.xa = xa; p.xb = cb ? xb : (xa_bf16 ? logits : xa);
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh1 = consts[0]; p.sh2 = consts[1]; p.sh3 = consts[2]; p.w4 = consts[3]; p.b4 = consts[4];
     p.logits = logits;
@@ -1246,6 +1262,18 @@ int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const flo
     else
         hipLaunchKernelGGL((fp_head_bf16_kernel<4, 1>), grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
     return check_launch("fpn_fp_head_chain_bf16");
+}
+
+int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const float *xb, const void *wstream,
+                           const float *const *consts, float *logits, void *stream)
+{
+    return fp_head_chain_bf16(rows, ca, cb, xa, 0, xb, wstream, consts, logits, stream);
+}
+
+int fpn_fp_head_chain_bf16x(long rows, int ca, int cb, const void *xa_bf16, const float *xb, const void *wstream,
+                            const float *const *consts, float *logits, void *stream)
+{
+    return fp_head_chain_bf16(rows, ca, cb, xa_bf16, 1, xb, wstream, consts, logits, stream);
 }
 
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,

@@ -552,10 +552,22 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_kernel(
 // (max(d,1e-10), reciprocal, left-to-right sum, divide: the op sequence of
 // pointnet_fp_module) and parks (indices, weights) in LDS; phase 2 has the
 // whole workgroup write the 256 output rows with lanes along the channel axis.
-template <int LW>
-__global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_kernel(
+// OutT = float, or __bf16: the same sums rounded to bf16 on the way out (round to nearest even,
+// the conversion a bf16 consumer would apply to the fp32 result itself).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store4(float *dst, int l, const float4 &t) { reinterpret_cast<float4 *>(dst)[l] = t; }
+__device__ __forceinline__ void store4(__bf16 *dst, int l, const float4 &t)
+{
+    bf16x4 v;
+    v[0] = (__bf16)t.x; v[1] = (__bf16)t.y; v[2] = (__bf16)t.z; v[3] = (__bf16)t.w;
+    reinterpret_cast<bf16x4 *>(dst)[l] = v;
+}
+
+template <int LW, class OutT>
+__device__ __forceinline__ void three_nn_interpolate_body(
     int n, int m, int c, int vec, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    const float *__restrict__ points2, float *__restrict__ out, float *__restrict__ dist,
+    const float *__restrict__ points2, OutT *__restrict__ out, float *__restrict__ dist,
     int *__restrict__ idx)
 {
     __shared__ float4 tile[kNnTile];
@@ -605,26 +617,43 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_kernel(
         const int i1 = s_i[r * 3 + 0], i2 = s_i[r * 3 + 1], i3 = s_i[r * 3 + 2];
         const float w1 = s_w[r * 3 + 0], w2 = s_w[r * 3 + 1], w3 = s_w[r * 3 + 2];
         const float *p1 = p + (size_t)i1 * c, *p2 = p + (size_t)i2 * c, *p3 = p + (size_t)i3 * c;
-        float *dst = out + ((size_t)bi * n + j0 + r) * c;
+        OutT *dst = out + ((size_t)bi * n + j0 + r) * c;
         if (vec) {       // c % 4 == 0 and 16-byte aligned arrays: the same sums, four channels per lane
             const float4 *q1 = reinterpret_cast<const float4 *>(p1), *q2 = reinterpret_cast<const float4 *>(p2),
                          *q3 = reinterpret_cast<const float4 *>(p3);
-            float4 *d4 = reinterpret_cast<float4 *>(dst);
             for (int l = lx; l < c / 4; l += LW) {
                 const float4 a = q1[l], bq = q2[l], cq = q3[l];
                 float4 t;
                 t.x = a.x * w1 + bq.x * w2; t.y = a.y * w1 + bq.y * w2;
                 t.z = a.z * w1 + bq.z * w2; t.w = a.w * w1 + bq.w * w2;
                 t.x = t.x + cq.x * w3; t.y = t.y + cq.y * w3; t.z = t.z + cq.z * w3; t.w = t.w + cq.w * w3;
-                d4[l] = t;
+                store4(dst, l, t);
             }
         } else {
             for (int l = lx; l < c; l += LW) {
                 float t = p1[l] * w1 + p2[l] * w2;
-                dst[l] = t + p3[l] * w3;
+                dst[l] = (OutT)(t + p3[l] * w3);
             }
         }
     }
+}
+
+template <int LW>
+__global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_kernel(
+    int n, int m, int c, int vec, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ points2, float *__restrict__ out, float *__restrict__ dist,
+    int *__restrict__ idx)
+{
+    three_nn_interpolate_body<LW>(n, m, c, vec, xyz1, xyz2, points2, out, dist, idx);
+}
+
+template <int LW>
+__global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_bf16_kernel(
+    int n, int m, int c, int vec, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ points2, __bf16 *__restrict__ out)
+{
+    three_nn_interpolate_body<LW>(n, m, c, vec, xyz1, xyz2, points2, out, static_cast<float *>(nullptr),
+                                  static_cast<int *>(nullptr));
 }
 
 // ---------------------------------------------------------------------------
@@ -973,6 +1002,23 @@ int fpn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1, cons
     FPN_DISPATCH_LW(lw, three_nn_interpolate_kernel, grid, dim3(kNnThreads), 0, st, n, m, c, vec, xyz1, xyz2,
                     points2, out, dist, idx)
     return check_launch("fpn_three_nn_interpolate");
+}
+
+int fpn_three_nn_interpolate_bf16(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
+                                  const float *points2, void *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 1, "three_nn_interpolate_bf16: bad size (m must be >= 1)");
+    if (b == 0 || n == 0) return FPN_OK;
+    FPN_REQUIRE(xyz1 && xyz2 && points2 && out, "three_nn_interpolate_bf16: null pointer");
+    FPN_REQUIRE(b <= 65535, "three_nn_interpolate_bf16: batch %d exceeds 65535", b);
+    const int vec = c > 0 && c % 4 == 0 && (reinterpret_cast<uintptr_t>(points2) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+    const int lw = pow2_at_least(c > 0 ? (vec ? c / 4 : c) : 1);
+    dim3 grid((n + kNnThreads - 1) / kNnThreads, b);
+    hipStream_t st = as_stream(stream);
+    FPN_DISPATCH_LW(lw, three_nn_interpolate_bf16_kernel, grid, dim3(kNnThreads), 0, st, n, m, c, vec, xyz1, xyz2,
+                    points2, static_cast<__bf16 *>(out))
+    return check_launch("fpn_three_nn_interpolate_bf16");
 }
 
 int fpn_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream)

@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class FpnError(RuntimeError):
@@ -43,6 +43,7 @@ SIGNATURES = {
     "fpn_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_three_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_three_nn_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fpn_three_nn_interpolate_bf16": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_select_top_k": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fpn_shared_mlp_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
     "fpn_mlp_pack_bf16": [_i, _i, _vp, _vp, _vp],
@@ -67,6 +68,7 @@ SIGNATURES = {
     "fpn_sa_chain_bf16": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_fp_head_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_fp_head_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fpn_fp_head_chain_bf16x": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_box3d_iou_f64": [_l, _vp, _l, _vp, _l, _vp, _vp],
     "fpn_box3d_intersection_f64": [_l, _vp, _l, _vp, _l, _vp, _vp, _vp],

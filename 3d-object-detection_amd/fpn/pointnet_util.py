@@ -27,6 +27,9 @@ FUSE_SA = True
 # Operand type of the fused kernel's matrix products: "fp32", or "bf16" (bf16 weights and
 # activations between the layers, fp32 accumulation; the per-layer path stays fp32).
 SA_PRECISION = "fp32"
+# Under SA_PRECISION = "bf16": the interpolated features of the last feature propagation reach
+# the fused head kernel as bf16 (False: as float, rounded by the head kernel - same results).
+INTERP_BF16 = True
 
 
 def group_concat(xyz, new_xyz, points, idx, xyz_first=True):
@@ -463,7 +466,11 @@ def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, 
     store = variables.get_default_store()
     with variables.variable_scope(scope):
         names = [variables.scoped('conv_0'), variables.scoped('conv_1')]
-        interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous())   # :210-215
+        # the bf16 kernel rounds its inputs to bf16 as it reads them: rounded on the way OUT of the
+        # interpolation instead, the same values cross memory in half the bytes (INTERP_BF16)
+        half = SA_PRECISION == "bf16" and INTERP_BF16
+        interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous(),
+                                            out_dtype=torch.bfloat16 if half else torch.float32)   # :210-215
     names += [variables.scoped(head_scope), variables.scoped(out_scope)]
     plan = _fp_head_plan(store, names, cb, bn)
     rows = b * n
@@ -475,9 +482,9 @@ def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, 
                     macs=rows * ((128 + cb) * 128 + 2 * 128 * 128 + 128 * 2)) if obs is not None else None
     with torch.cuda.device(xyz1.device):
         if "stream" in plan:
-            _lib.check(lib.fpn_fp_head_chain_bf16(rows, 128, cb, _lib.ptr(interpolated), _lib.ptr(xb),
-                                                  _lib.ptr(plan["stream"]), plan["table"], _lib.ptr(logits),
-                                                  _lib.stream_of(xyz1)))
+            entry = lib.fpn_fp_head_chain_bf16x if interpolated.dtype == torch.bfloat16 else lib.fpn_fp_head_chain_bf16
+            _lib.check(entry(rows, 128, cb, _lib.ptr(interpolated), _lib.ptr(xb), _lib.ptr(plan["stream"]),
+                             plan["table"], _lib.ptr(logits), _lib.stream_of(xyz1)))
         else:
             _lib.check(lib.fpn_fp_head_chain_f32(rows, 128, cb, _lib.ptr(interpolated), _lib.ptr(xb), plan["table"],
                                                  _lib.ptr(logits), _lib.stream_of(xyz1)))

@@ -45,11 +45,13 @@ def three_interpolate(points, idx, weight):
     return out
 
 
-def three_nn_interpolate(xyz1, xyz2, points2, return_neighbours=False):
+def three_nn_interpolate(xyz1, xyz2, points2, return_neighbours=False, out_dtype=torch.float32):
     """Fused three_nn -> inverse-distance weights (models/pointnet_util.py:211-214)
     -> three_interpolate.  xyz1 (B,N,3), xyz2 (B,M,3), points2 (B,M,C) -> (B,N,C);
     with return_neighbours also dist (B,N,3) and idx (B,N,3).  Same values as the
-    three separate calls; the neighbour table stays on chip unless requested."""
+    three separate calls; the neighbour table stays on chip unless requested.
+    out_dtype=torch.bfloat16: the same sums rounded to bf16 on the way out (for a consumer
+    that reads bf16 operands; no neighbour table)."""
     _lib.require_device_tensor("xyz1", xyz1, torch.float32, 3, 3)
     _lib.require_device_tensor("xyz2", xyz2, torch.float32, 3, 3)
     _lib.require_device_tensor("points2", points2, torch.float32, 3)
@@ -61,6 +63,16 @@ def three_nn_interpolate(xyz1, xyz2, points2, return_neighbours=False):
         raise ValueError("three_nn_interpolate expects at least one known point")
     _lib.same_device(xyz1, xyz2, points2)
     c = points2.shape[2]
+    if out_dtype == torch.bfloat16:
+        if return_neighbours:
+            raise ValueError("the bf16 form of three_nn_interpolate returns no neighbour table")
+        out = torch.empty((b, n, c), dtype=torch.bfloat16, device=xyz1.device)
+        with torch.cuda.device(xyz1.device):
+            _lib.check(_lib.load().fpn_three_nn_interpolate_bf16(b, n, m, c, _lib.ptr(xyz1), _lib.ptr(xyz2),
+                                                                 _lib.ptr(points2), _lib.ptr(out), _lib.stream_of(xyz1)))
+        return out
+    if out_dtype != torch.float32:
+        raise ValueError("out_dtype must be torch.float32 or torch.bfloat16")
     out = torch.empty((b, n, c), dtype=torch.float32, device=xyz1.device)
     dist = idx = None
     if return_neighbours:

@@ -133,6 +133,11 @@ int fpn_three_interpolate(int b, int m, int c, int n, const float *points, const
 int fpn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
                              const float *points2, float *out, float *dist, int *idx,
                              void *stream);
+/* fpn_three_nn_interpolate with the result rounded to bf16 (round to nearest even) on the
+ * way out: out (b,n,c) bf16; no neighbour table.  For a consumer that reads bf16 operands
+ * (fpn_fp_head_chain_bf16x).  Same reference lines as fpn_three_nn_interpolate. */
+int fpn_three_nn_interpolate_bf16(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
+                                  const float *points2, void *out, void *stream);
 
 /*
  * Partial selection sort of each row of dist (b,m,n): out = dist with the k
@@ -473,6 +478,12 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
 int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const float *xb,
                            const void *wstream, const float *const *consts, float *logits,
                            void *stream);
+/* The same with the interpolated features already in bf16 (fpn_three_nn_interpolate_bf16's
+ * output: (rows, ca) bf16 row-major, 16-byte aligned): half the bytes between the two
+ * kernels, the same logits bit for bit (the kernel rounds fp32 rows to bf16 itself). */
+int fpn_fp_head_chain_bf16x(long rows, int ca, int cb, const void *xa_bf16, const float *xb,
+                            const void *wstream, const float *const *consts, float *logits,
+                            void *stream);
 
 /*
  * Mask, masked centroid and object-point gather of point_cloud_masking +

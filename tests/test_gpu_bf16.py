@@ -319,3 +319,33 @@ def test_bf16_tiled_layer(device, rows, cin, cout, pool, gb):
                 v = v.reshape(rows // pool, pool, cout).max(axis=1)
             assert scaled_err(got.cpu().numpy(), v) <= 1e-4          # fp32 accumulation of exact bf16 products
             assert scaled_err(got.cpu().numpy(), want32.cpu().numpy()) <= BF16_RTOL
+
+
+def test_bf16_interpolation_output_feeds_the_head_bit_for_bit(device):
+    """Under bf16 the last feature propagation hands its interpolated features to the fused
+    head kernel as bf16 (fpn_three_nn_interpolate_bf16 -> fpn_fp_head_chain_bf16x) instead of
+    float rows that the head rounds itself: the same logits, bit for bit; and the bf16
+    interpolation equals the float one rounded to nearest even."""
+    from fpn import pointnet_util as U
+    from fpn import synthetic, variables
+    from fpn.models import frustum_pointnets_v2 as M2
+    from fpn.tf_ops.tf_interpolate import three_nn_interpolate
+    rng = np.random.RandomState(3)
+    xyz1, xyz2 = rng.random_sample((3, 700, 3)).astype(np.float32), rng.random_sample((3, 50, 3)).astype(np.float32)
+    for c in (128, 6):
+        pts = rng.standard_normal((3, 50, c)).astype(np.float32)
+        f32 = three_nn_interpolate(dev(xyz1, device), dev(xyz2, device), dev(pts, device))
+        b16 = three_nn_interpolate(dev(xyz1, device), dev(xyz2, device), dev(pts, device), out_dtype=torch.bfloat16)
+        assert torch.equal(b16, f32.bfloat16())
+    pc, oh = synthetic.make_frustums(3, 2048, 4, seed=5)
+    pc[..., :3] *= 0.05
+    st = variables.VariableStore(device, seed=2)
+    got = {}
+    for flag in (True, False, True):
+        U.SA_PRECISION, U.INTERP_BF16 = "bf16", flag
+        try:
+            with variables.use_store(st):
+                got[flag] = M2.get_model(dev(pc, device), dev(oh, device), False)["mask_logits"].clone()
+        finally:
+            U.SA_PRECISION, U.INTERP_BF16 = "fp32", True
+    assert torch.equal(got[True], got[False])
