@@ -812,6 +812,7 @@ struct SaParams {
     long rows;
     int n, m, ns, cf;
     const float *xyz, *new_xyz, *feat;
+    const bf16x8 *featp;                // NJF > 0: the features packed by fpn_sa_pack_features_bf16, or NULL (then feat)
     const int *idx;
     const float *w1, *sc1, *sh1;        // NJF = 0 only: (3+cf, 32 NT1) fp32, scale, shift
     const bf16x8 *ws;
@@ -860,17 +861,25 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
             const float *src = p.xyz + (b * p.n + pid[g]) * 3;
-            const float *f = p.feat + (b * p.n + pid[g]) * (long)p.cf;
+            if (p.featp) {      // (kernel-uniform) operand fragments as they lie in memory: half the gathered bytes, no conversion
+                const bf16x8 *f = p.featp + (b * p.n + pid[g]) * (long)(4 * NJF);
 #pragma unroll
-            for (int t = 0; t < NJF; ++t)
+                for (int t = 0; t < NJF; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4 *>(f + 32 * t + 8 * q + 4 * h);
-                    in[g][t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
-                    in[g][t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
-                    in[g][t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
-                    in[g][t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
-                }
+                    for (int s = 0; s < 2; ++s) in[g][t].m[s] = f[(2 * t + s) * 2 + h];
+            } else {
+                const float *f = p.feat + (b * p.n + pid[g]) * (long)p.cf;
+#pragma unroll
+                for (int t = 0; t < NJF; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(f + 32 * t + 8 * q + 4 * h);
+                        in[g][t].m[q >> 1][4 * (q & 1) + 0] = (__bf16)v.x;
+                        in[g][t].m[q >> 1][4 * (q & 1) + 1] = (__bf16)v.y;
+                        in[g][t].m[q >> 1][4 * (q & 1) + 2] = (__bf16)v.z;
+                        in[g][t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
+                    }
+            }
             // channels 0..2 of the last tile: elements 0..2 of fragment 0 in the lower lane half
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -881,13 +890,17 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
             in[g][NJF].m[0][2] = (__bf16)(h == 0 ? src[2] - ctr[2] : 0.f);
         }
         __builtin_amdgcn_sched_barrier(0);
+        FPN_STAMP(1);
         constexpr int U1 = (NT1 / 2) * NJ1, U2 = (NT2 / 2) * NT1;
         layer_t<NP, NJ1, NT1, 0>(a1, in, ws, p.shs1, feed, h);
+        FPN_STAMP(2);
         ws += U1 * kUnitVecs;
         layer_t<NP, NT1, NT2, U1 % kRing>(a2, a1, ws, p.sh2, feed, h);
+        FPN_STAMP(3);
         ws += U2 * kUnitVecs;
         if (pool.on) layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane, p.c3);
         else layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, gmax, feed, lane, p.c3);
+        FPN_STAMP(4);
     } else {
         FirstLayer<NT1, 4> first;
         first.load(p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.out, p.ldo, p.c3);
 #ifdef FPN_SA_STAMPS
     stamp[5] = clock64();
-    if (NJF == 0 && blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
+    if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
         for (int i = 0; i < 6; ++i) reinterpret_cast<long long *>(p.out)[i] = stamp[i];
 #endif
 }
@@ -1013,6 +1026,24 @@ __global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadP
         s1 += __shfl_xor(s1, 32);
         if (h == 0)
             *reinterpret_cast<float2 *>(p.logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + p.b4[0], s1 + p.b4[1]);
+    }
+}
+
+// Point features (points, cf) fp32, cf a multiple of 32 -> the operand fragments a lane of the
+// set-abstraction kernel holds for that point: vector ((2 t + s) * 2 + h) of a point = the 8
+// channels 32 t + 16 s + 8 (e >> 2) + 4 h + (e & 3), e = 0..7, rounded to bf16.
+__global__ void pack_features_kernel(long vecs, int cf, const float *__restrict__ feat, bf16x8 *__restrict__ dst)
+{
+    const int per = cf / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (long)gridDim.x * blockDim.x) {
+        const long pnt = i / per;
+        const int v = (int)(i % per), h = v & 1, s = (v >> 1) & 1, t = v >> 2;
+        const float *src = feat + pnt * cf + 32 * t + 16 * s + 4 * h;
+        const float4 a = *reinterpret_cast<const float4 *>(src), c = *reinterpret_cast<const float4 *>(src + 8);
+        bf16x8 o;
+        o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+        o[4] = (__bf16)c.x; o[5] = (__bf16)c.y; o[6] = (__bf16)c.z; o[7] = (__bf16)c.w;
+        dst[i] = o;
     }
 }
 
@@ -1276,9 +1307,23 @@ int fpn_fp_head_chain_bf16x(long rows, int ca, int cb, const void *xa_bf16, cons
     return fp_head_chain_bf16(rows, ca, cb, xa_bf16, 1, xb, wstream, consts, logits, stream);
 }
 
-int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                      const float *new_xyz, const float *feat, const int *idx, const void *wstream,
-                      const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
+int fpn_sa_pack_features_bf16(long points, int cf, const float *feat, void *packed, void *stream)
+{
+    FPN_REQUIRE(points >= 0 && cf >= 32 && cf % 32 == 0, "sa_pack_features_bf16: cf (%d) must be a positive multiple of 32", cf);
+    if (points == 0) return FPN_OK;
+    FPN_REQUIRE(feat && packed, "sa_pack_features_bf16: null pointer");
+    FPN_REQUIRE(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(packed)) & 15) == 0,
+                "sa_pack_features_bf16: arrays must be 16-byte aligned");
+    const long vecs = points * (cf / 8);
+    hipLaunchKernelGGL(pack_features_kernel, dim3((unsigned)std::min<long>((vecs + 255) / 256, 1 << 20)), dim3(256), 0,
+                       as_stream(stream), vecs, cf, feat, static_cast<bf16x8 *>(packed));
+    return check_launch("fpn_sa_pack_features_bf16");
+}
+
+static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                         const float *new_xyz, const float *feat, const void *feat_packed, const int *idx,
+                         const void *wstream, const float *const *consts, float *out, int ldo, int c3_valid,
+                         void *stream)
 {
     FPN_REQUIRE(b >= 0 && n >= 1 && m >= 1 && ns >= 1 && cf >= 0, "sa_chain_bf16: bad size");
     FPN_REQUIRE(ns % 32 == 0, "sa_chain_bf16: samples per ball (%d) must be a multiple of 32", ns);
@@ -1289,11 +1334,14 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
     if ((c2 % 64 != 0 && !(cf < 32 && c1 == 64 && c2 == 96 && c3 == 128)) || !fpn_sa_chain_supported(cf, c1, c2, c3))
         return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
     if (b == 0) return FPN_OK;
-    FPN_REQUIRE(xyz && new_xyz && idx && wstream && consts && out && (cf == 0 || feat), "sa_chain_bf16: null pointer");
+    FPN_REQUIRE(xyz && new_xyz && idx && wstream && consts && out && (cf == 0 || feat || feat_packed), "sa_chain_bf16: null pointer");
+    FPN_REQUIRE(!feat_packed || (cf >= 32 && (reinterpret_cast<uintptr_t>(feat_packed) & 15) == 0),
+                "sa_chain_bf16: packed features need cf >= 32 and a 16-byte aligned array");
     const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32;
     SaParams p{};
     p.rows = (long)b * m * ns; p.n = n; p.m = m; p.ns = ns; p.cf = cf;
     p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.idx = idx;
+    p.featp = static_cast<const bf16x8 *>(feat_packed);
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     if (njf == 0) {       // consts: w1, scale1, shift1, shift2, shift3
         for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "sa_chain_bf16: constant %d is null", i);
@@ -1310,6 +1358,23 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
     if (njf == 10 && t1 == 2) return launch_sa<10, 2, 2, 4>(p, st);
     if (njf == 10) return launch_sa<10, 4, 4, 8>(p, st);
     return launch_sa<4, 4, 4, 8>(p, st);
+}
+
+int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                      const float *new_xyz, const float *feat, const int *idx, const void *wstream,
+                      const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
+{
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, idx, wstream, consts, out, ldo, c3_valid,
+                         stream);
+}
+
+int fpn_sa_chain_bf16p(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                       const float *new_xyz, const void *feat_packed, const int *idx, const void *wstream,
+                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
+{
+    FPN_REQUIRE(cf >= 32, "sa_chain_bf16p: packed features exist for cf >= 32 only (cf = %d)", cf);
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, nullptr, feat_packed, idx, wstream, consts, out, ldo,
+                         c3_valid, stream);
 }
 
 }  // extern "C"

@@ -197,7 +197,24 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     return plan
 
 
-def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first, zeroed=False):
+# Under SA_PRECISION = "bf16": point features wider than 32 channels are converted to the
+# kernel's operand form once per module instead of once per gathered row (False: gathered as
+# float and converted in the kernel - same results).
+PACK_FEATURES = True
+
+
+def _pack_features(points):
+    """(B,N,C) float32 features, C a multiple of 32 -> fpn_sa_pack_features_bf16's table."""
+    points = points.contiguous()
+    b, n, c = points.shape
+    packed = torch.empty((b, n, c), dtype=torch.bfloat16, device=points.device)
+    with torch.cuda.device(points.device):
+        _lib.check(_lib.load().fpn_sa_pack_features_bf16(b * n, c, _lib.ptr(points), _lib.ptr(packed),
+                                                         _lib.stream_of(points)))
+    return packed
+
+
+def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first, zeroed=False, packed=None):
     """Grouping + 3-layer MLP + max over the samples in one kernel (fpn_sa_chain_f32).
     out2d (b*m, widths[-1]) may be a column slice of a wider buffer; the kernel merges its
     maxima into it, so it must start at zero (`zeroed`: the caller has cleared it).  Returns
@@ -224,10 +241,12 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
                         b * m * ns, 0, 0, macs=b * m * ns * macs)
     with torch.cuda.device(xyz.device):
         if "stream" in plan:
-            _lib.check(_lib.load().fpn_sa_chain_bf16(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
-                                                     _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx),
-                                                     _lib.ptr(plan["stream"]), plan["table"], _lib.ptr(out2d), ldo,
-                                                     int(widths[2]), _lib.stream_of(xyz)))
+            if packed is None and PACK_FEATURES and cf >= 32 and cf % 32 == 0:
+                packed = _pack_features(points)
+            entry = _lib.load().fpn_sa_chain_bf16 if packed is None else _lib.load().fpn_sa_chain_bf16p
+            _lib.check(entry(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz), _lib.ptr(new_xyz),
+                             _lib.ptr(points if packed is None else packed), _lib.ptr(idx), _lib.ptr(plan["stream"]),
+                             plan["table"], _lib.ptr(out2d), ldo, int(widths[2]), _lib.stream_of(xyz)))
         else:
             _lib.check(_lib.load().fpn_sa_chain_f32(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
                                                     _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx), plan["table"],
@@ -355,6 +374,10 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         width = sum(w[-1] for w in mlp_list)
         # (one clear for all scales: the fused kernels merge their maxima into it)
         out = torch.zeros((b * m, width), dtype=torch.float32, device=xyz.device)
+        packed = None
+        if SA_PRECISION == "bf16" and PACK_FEATURES and FUSE_SA and points is not None and use_xyz \
+                and points.shape[2] >= 32 and points.shape[2] % 32 == 0:
+            packed = _pack_features(points)       # one table for all scales
         col = 0
         for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
             idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
@@ -362,7 +385,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             if (points is None or use_xyz) and FUSE_SA and \
                     _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx, mlp_list[i],
                               'conv%d_' % i + '%d', bn, out[:, col:col + w_i], xyz_first=False,
-                              zeroed=True):                                                      # :176-192 in one kernel
+                              zeroed=True, packed=packed):                                                      # :176-192 in one kernel
                 col += w_i
                 continue
             if points is not None and use_xyz:

@@ -473,6 +473,17 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                       const float *new_xyz, const float *feat, const int *idx, const void *wstream,
                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream);
+/* The same for cf >= 32 with the point features converted once instead of once per gathered
+ * row: fpn_sa_pack_features_bf16 turns feat (points, cf) fp32 (cf % 32 == 0, 16-byte
+ * aligned) into `packed` (points * cf bf16, an internal operand order, meaningful only to
+ * fpn_sa_chain_bf16p).  Same results bit for bit; half the gathered bytes (the modules of a
+ * multi-scale set abstraction gather the same table several times,
+ * models/pointnet_util.py:176-183). */
+int fpn_sa_pack_features_bf16(long points, int cf, const float *feat, void *packed, void *stream);
+int fpn_sa_chain_bf16p(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                       const float *new_xyz, const void *feat_packed, const int *idx,
+                       const void *wstream, const float *const *consts, float *out, int ldo,
+                       int c3_valid, void *stream);
 /* fpn_fp_head_chain_f32 in bf16: stream: layer 1 (the padded (160,128) matrix), layer 2,
  * layer 3; consts {shift1, shift2, shift3, w4 (128,2) fp32, bias4}. */
 int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const float *xb,

@@ -349,3 +349,35 @@ def test_bf16_interpolation_output_feeds_the_head_bit_for_bit(device):
         finally:
             U.SA_PRECISION, U.INTERP_BF16 = "fp32", True
     assert torch.equal(got[True], got[False])
+
+
+def test_bf16_packed_features_bit_for_bit(device):
+    """Set abstraction in bf16 over wide point features: gathered as float and converted per
+    row in the kernel, or converted once into the operand order and gathered as bf16
+    (fpn_sa_pack_features_bf16 -> fpn_sa_chain_bf16p): the same bits, for the multi-scale
+    module (one table for all scales) and the single-scale one."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(8)
+    b = 3
+    xyz = rng.uniform(0, 1, (b, 128, 3)).astype(np.float32)
+    cases = [("msg", rng.standard_normal((b, 128, 320)).astype(np.float32),
+              (32, [0.4, 0.8, 1.6], [64, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]])),
+             ("ssg", rng.standard_normal((b, 128, 128)).astype(np.float32), (32, 0.4, 64, [128, 128, 256]))]
+    for kind, pts, args in cases:
+        st = variables.VariableStore(device, seed=6)
+        got = {}
+        for flag in (True, False, True):
+            U.SA_PRECISION, U.PACK_FEATURES = "bf16", flag
+            try:
+                with variables.use_store(st):
+                    if kind == "msg":
+                        _, feat = U.pointnet_sa_module_msg(dev(xyz, device), dev(pts, device), *args, False, None, scope='s')
+                    else:
+                        _, feat, _ = U.pointnet_sa_module(dev(xyz, device), dev(pts, device), *args, None, False, False, None,
+                                                          scope='s')
+            finally:
+                U.SA_PRECISION, U.PACK_FEATURES = "fp32", True
+            got[flag] = feat.clone()
+        assert torch.equal(got[True], got[False]), kind
+        assert got[True].abs().max() > 0

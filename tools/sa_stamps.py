@@ -31,6 +31,20 @@ def main():
             t = out.reshape(-1)[:12].view(torch.int64).cpu().tolist()
             print("scale %d %s ns=%d:" % (i, s["mlp"][i], s["nsample"][i]),
                   ", ".join("%s +%d" % (names[k], t[k] - t[k - 1]) for k in range(1, 6)), "| total", t[5] - t[0])
+        # the second multi-scale module: 128 points with 320 features each, 32 balls
+        s2 = M2.CONFIG["seg"]["sa2"]
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1)
+        xyz2 = xyz[:, :128].contiguous()
+        feat2 = torch.randn((xyz.shape[0], 128, 320), device=dev, generator=gen)
+        for i in range(len(s2["radius"])):
+            for _ in range(3):
+                _, out = pointnet_util.pointnet_sa_module_msg(xyz2, feat2, s2["npoint"], [s2["radius"][i]], [s2["nsample"][i]],
+                                                              [s2["mlp"][i]], False, None, scope="probe2%d" % i)
+            torch.cuda.synchronize()
+            t = out.reshape(-1)[:12].view(torch.int64).cpu().tolist()
+            print("sa2 scale %d %s ns=%d:" % (i, s2["mlp"][i], s2["nsample"][i]),
+                  ", ".join("%s +%d" % (names[k], t[k] - t[k - 1]) for k in range(1, 6)), "| total", t[5] - t[0])
 
 
 if __name__ == "__main__":
