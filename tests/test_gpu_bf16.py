@@ -285,8 +285,8 @@ def test_bf16_tiled_layer(device, rows, cin, cout, pool, gb):
     random data it stays within the bf16 bound of the float64 product of the rounded operands."""
     from fpn import ops
     rng = np.random.RandomState(rows + cin)
-    ldx = cin + 3
-    for kind in ("int", "real"):
+    # row stride off and on a 16-byte multiple (scalar and vector loads of x)
+    for kind, ldx in (("int", cin + 3), ("real", cin + 3), ("int", (cin + 3) // 4 * 4 + 4)):
         if kind == "int":
             x = rng.randint(-3, 4, (rows, ldx)).astype(np.float32)
             w = rng.randint(-2, 3, (cin, cout)).astype(np.float32)
