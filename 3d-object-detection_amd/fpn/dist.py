@@ -39,17 +39,22 @@ def unpack_results(records, num_point=None):
     return out
 
 
-def gather_results(records, group=None, out=None):
+def gather_results(records, group=None, out=None, async_op=False):
     """All-gather equal-sized per-rank record blocks -> (world*B_local, width) on every
-    rank, rank-major (so with shard_range the global frustum order is preserved)."""
+    rank, rank-major (so with shard_range the global frustum order is preserved).
+    async_op=True returns (out, work): the collective runs on the backend's own stream and the
+    caller's stream does not wait for it - the next batch's kernels overlap the gather; call
+    work.wait() (None for a single rank) before reading `out`.  RCCL runs successive gathers
+    in issue order on its stream, so they may share one `out`; a backend without that order
+    (gloo) needs the previous one waited for first."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return records
+        return (records, None) if async_op else records
     world = dist.get_world_size(group)
     if out is None:
         out = torch.empty((world * records.shape[0], records.shape[1]), dtype=records.dtype,
                           device=records.device)
-    dist.all_gather_into_tensor(out, records, group=group)
-    return out
+    work = dist.all_gather_into_tensor(out, records, group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def gather_ragged(records, total, group=None):
@@ -74,7 +79,7 @@ def gather_ragged(records, total, group=None):
 STATS = 30      # width of the Monte-Carlo ensemble statistics table (fpn_mc_statistics)
 
 
-def gather_statistics(stats, total=None, group=None, out=None):
+def gather_statistics(stats, total=None, group=None, out=None, async_op=False):
     """Monte-Carlo ensembles: every rank keeps all samples of its own frustums, reduces them
     to the (frustums, STATS) statistics table on its device and only that table travels:
     one all-gather -> (total, STATS) on every rank in global frustum order.  `total`: size
@@ -82,7 +87,9 @@ def gather_statistics(stats, total=None, group=None, out=None):
     if stats.dim() != 2 or stats.shape[1] != STATS:
         raise ValueError("expected a (frustums, %d) statistics table, got %s" % (STATS, tuple(stats.shape)))
     if total is None:
-        return gather_results(stats.contiguous(), group, out)
+        return gather_results(stats.contiguous(), group, out, async_op=async_op)
+    if async_op:
+        raise ValueError("the ragged statistics gather has no asynchronous form")
     return gather_ragged(stats.contiguous(), total, group)
 
 

@@ -496,6 +496,7 @@ def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
     step = wl["step"]
     bf16 = args.dtype == "bf16"
     gathered = [None]
+    last_work = [None]
 
     def full_step():
         rec = step()
@@ -504,12 +505,18 @@ def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
                 rec = rec.cpu()
             elif gathered[0] is None:
                 gathered[0] = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=dev)
+            # RCCL: the gather runs on the backend's stream beside the next step's kernels (the
+            # fence at the end of the timed region waits for every stream); gloo: synchronous
             if wl["gather"] == "statistics":
-                fdist.gather_statistics(rec, out=gathered[0])
+                res = fdist.gather_statistics(rec, out=gathered[0], async_op=not REHEARSAL)
             else:
-                fdist.gather_results(rec, out=gathered[0])
+                res = fdist.gather_results(rec, out=gathered[0], async_op=not REHEARSAL)
+            last_work[0] = None if REHEARSAL else res[1]
 
     def fence():
+        if last_work[0] is not None:
+            last_work[0].wait()
+            last_work[0] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

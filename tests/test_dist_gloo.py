@@ -34,6 +34,18 @@ def _worker(rank, world, port, total, out_dir):
     if total % world == 0:
         same = fdist.gather_results(rec)
         assert torch.equal(same, full)
+        # the asynchronous form (gloo runs its operations on worker threads in no fixed order:
+        # one gather into a buffer at a time; RCCL orders them on its stream)
+        buf = torch.empty_like(full)
+        _, w1 = fdist.gather_results(rec + 1.0, out=buf, async_op=True)
+        w1.wait()
+        assert torch.equal(buf, full + 1.0)
+        out2, w2 = fdist.gather_results(rec, out=buf, async_op=True)
+        w2.wait()
+        assert out2 is buf and torch.equal(buf, full)
+        st_out, w3 = fdist.gather_statistics(ids[:, None] + torch.zeros(fdist.STATS)[None], async_op=True)
+        w3.wait()
+        assert torch.equal(st_out[:, 0], torch.arange(total, dtype=torch.float32))
     # Monte-Carlo ensembles: the per-frustum statistics tables are what travels
     stats = ids[:, None] * 2 + torch.arange(fdist.STATS)[None] / 10.0
     full_s = fdist.gather_statistics(stats, total)

@@ -30,6 +30,16 @@ def main():
     torch.cuda.synchronize()
     print("first all_gather %.1f s" % (time.time() - t0), flush=True)
     assert torch.equal(out, rec)
+    # the bench's pattern: asynchronous gathers into one buffer beside further work on the
+    # compute stream, the last one waited for at the end
+    work = None
+    for i in range(5):
+        rec_i = rec + float(i)
+        work = dist.all_gather_into_tensor(out, rec_i, async_op=True)
+        rec = rec * 1.0
+    work.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(out, rec + 4.0)
     stats = torch.randn((64, fdist.STATS), device=dev)
     out2 = torch.empty_like(stats)
     dist.all_gather_into_tensor(out2, stats)
