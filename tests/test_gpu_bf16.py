@@ -363,7 +363,10 @@ def test_bf16_packed_features_bit_for_bit(device):
     xyz = rng.uniform(0, 1, (b, 128, 3)).astype(np.float32)
     cases = [("msg", rng.standard_normal((b, 128, 320)).astype(np.float32),
               (32, [0.4, 0.8, 1.6], [64, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]])),
-             ("ssg", rng.standard_normal((b, 128, 128)).astype(np.float32), (32, 0.4, 64, [128, 128, 256]))]
+             ("ssg", rng.standard_normal((b, 128, 128)).astype(np.float32), (32, 0.4, 64, [128, 128, 256])),
+             # one point group per wave (32 samples), and workgroups that end inside the last ball's rows
+             ("ssg", rng.standard_normal((b, 128, 320)).astype(np.float32), (7, 0.5, 32, [128, 128, 256])),
+             ("ssg", rng.standard_normal((b, 128, 128)).astype(np.float32), (5, 0.6, 32, [128, 128, 256]))]
     for kind, pts, args in cases:
         st = variables.VariableStore(device, seed=6)
         got = {}
