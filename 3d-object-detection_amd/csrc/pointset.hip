@@ -382,6 +382,119 @@ __global__ __launch_bounds__(kQbThreads) void query_ball_kernel(
     }
 }
 
+// Ball query for the NR radii of a multi-scale set abstraction (models/pointnet_util.py:
+// 176-178 calls query_ball_point once per radius on the same xyz / new_xyz) in ONE sweep:
+// the tile is staged once and every point pair's squared distance is formed once, then
+// tested against each radius that still has free slots; per radius the slot order, the
+// early stop at nsample hits and the padding are those of query_ball_kernel, so each
+// output equals the single-radius launch bit for bit.
+constexpr int kQbMaxRadii = 4;
+struct QbMulti {
+    float smax[kQbMaxRadii];
+    int nsample[kQbMaxRadii];
+    int *idx[kQbMaxRadii];
+    int *pts_cnt[kQbMaxRadii];
+};
+
+template <int NR>
+__global__ __launch_bounds__(kQbThreads) void query_ball_multi_kernel(
+    int n, int m, int qpb, int tile_pts, const float *__restrict__ xyz1, const float *__restrict__ xyz2, const QbMulti p)
+{
+    extern __shared__ float smem[];
+    constexpr int W = kQbThreads / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BlockXY blk = frustum_major_block();
+    const int bi = blk.y;
+    const float *data = xyz1 + (size_t)bi * n * 3;
+    const float *query = xyz2 + (size_t)bi * m * 3;
+    const int q0 = blk.x * qpb, q1 = min(m, q0 + qpb);
+    float *tx = smem, *ty = smem + tile_pts, *tz = smem + 2 * tile_pts;
+    int *s_cnt = reinterpret_cast<int *>(smem + tile_pts * 3);   // [NR][qpb]
+    int *s_first = s_cnt + NR * qpb;                             // [NR][qpb]
+
+    for (int i = tid; i < NR * qpb; i += kQbThreads) {
+        s_cnt[i] = 0;
+        s_first[i] = 0;
+    }
+    for (int t0 = 0; t0 < n; t0 += tile_pts) {
+        const int tn = min(tile_pts, n - t0);
+        __syncthreads();
+        for (int i = tid; i < tn * 3; i += kQbThreads) {
+            const int pnt = i / 3;
+            smem[(i - 3 * pnt) * tile_pts + pnt] = data[(size_t)t0 * 3 + i];
+        }
+        __syncthreads();
+
+        for (int q = q0 + wave; q < q1; q += W) {
+            int cnt[NR], first[NR];
+            bool open = false;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                cnt[r] = s_cnt[r * qpb + q - q0];
+                first[r] = s_first[r * qpb + q - q0];
+                open = open || cnt[r] < p.nsample[r];
+            }
+            if (!open) continue;
+            const float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
+            for (int kb = 0; kb < tn && open; kb += 2 * kWave) {
+                const int k = kb + 2 * lane;
+                float2v sq = {INFINITY, INFINITY};      // beyond the tile: no radius accepts it
+                if (k < tn) {
+                    const float2v px = *reinterpret_cast<const float2v *>(tx + k);
+                    const float2v py = *reinterpret_cast<const float2v *>(ty + k);
+                    const float2v pz = *reinterpret_cast<const float2v *>(tz + k);
+                    const float2v dx = qx - px, dy = qy - py, dz = qz - pz;
+                    sq = dx * dx + dy * dy;
+                    sq = sq + dz * dz;
+                    if (k + 1 >= tn) sq[1] = INFINITY;
+                }
+                open = false;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    if (cnt[r] < p.nsample[r]) {        // (wave-uniform)
+                        const bool hit0 = sq[0] <= p.smax[r], hit1 = sq[1] <= p.smax[r];
+                        const unsigned long long h0 = __ballot(hit0), h1 = __ballot(hit1);
+                        if (h0 | h1) {
+                            if (cnt[r] == 0) {
+                                const int f0 = h0 ? 2 * (int)__builtin_ctzll(h0) : 0x7fffffff;
+                                const int f1 = h1 ? 2 * (int)__builtin_ctzll(h1) + 1 : 0x7fffffff;
+                                first[r] = t0 + kb + min(f0, f1);
+                            }
+                            const unsigned long long below = (1ull << lane) - 1ull;
+                            const int slot0 = cnt[r] + __popcll(h0 & below) + __popcll(h1 & below);
+                            const int slot1 = slot0 + (hit0 ? 1 : 0);
+                            int *row = p.idx[r] + ((size_t)bi * m + q) * p.nsample[r];
+                            if (hit0 && slot0 < p.nsample[r]) row[slot0] = t0 + k;
+                            if (hit1 && slot1 < p.nsample[r]) row[slot1] = t0 + k + 1;
+                            cnt[r] += __popcll(h0) + __popcll(h1);
+                        }
+                        open = open || cnt[r] < p.nsample[r];
+                    }
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    s_cnt[r * qpb + q - q0] = cnt[r];
+                    s_first[r * qpb + q - q0] = first[r];
+                }
+            }
+        }
+    }
+
+    for (int q = q0 + wave; q < q1; q += W) {
+        __builtin_amdgcn_wave_barrier();       // (written by lane 0 of this same wave: LDS operations of a wave are in order)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int cnt = min(s_cnt[r * qpb + q - q0], p.nsample[r]);
+            const int first = s_first[r * qpb + q - q0];
+            int *row = p.idx[r] + ((size_t)bi * m + q) * p.nsample[r];
+            for (int l = cnt + lane; l < p.nsample[r]; l += kWave) row[l] = first;
+            if (p.pts_cnt[r] && lane == 0) p.pts_cnt[r][(size_t)bi * m + q] = cnt;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // group_point / three_interpolate share one thread mapping: LW lanes walk the
 // channels of a row (LW = power of two covering min(c,64)), 256/LW rows per
@@ -920,6 +1033,42 @@ int fpn_query_ball_point(int b, int n, int m, float radius, int nsample, const f
     hipLaunchKernelGGL(query_ball_kernel, grid, dim3(kQbThreads), lds, as_stream(stream), n, m,
                        ball_threshold(radius), nsample, qpb, tile_pts, xyz1, xyz2, idx, pts_cnt);
     return check_launch("fpn_query_ball_point");
+}
+
+int fpn_query_ball_point_multi(int b, int n, int m, int nr, const float *radii, const int *nsamples,
+                               const float *xyz1, const float *xyz2, int *const *idx, int *const *pts_cnt,
+                               void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "query_ball_point_multi: negative size");
+    FPN_REQUIRE(nr >= 1 && nr <= kQbMaxRadii, "query_ball_point_multi: 1 to %d radii (%d)", kQbMaxRadii, nr);
+    FPN_REQUIRE(radii && nsamples && idx, "query_ball_point_multi: null pointer");
+    QbMulti p{};
+    for (int r = 0; r < nr; ++r) {
+        FPN_REQUIRE(radii[r] > 0.f, "QueryBallPoint expects positive radius");
+        FPN_REQUIRE(nsamples[r] > 0, "QueryBallPoint expects positive nsample");
+        p.smax[r] = ball_threshold(radii[r]);
+        p.nsample[r] = nsamples[r];
+        p.idx[r] = idx[r];
+        p.pts_cnt[r] = pts_cnt ? pts_cnt[r] : nullptr;
+    }
+    if (b == 0 || m == 0) return FPN_OK;
+    FPN_REQUIRE(xyz1 && xyz2, "query_ball_point_multi: null pointer");
+    for (int r = 0; r < nr; ++r) FPN_REQUIRE(idx[r], "query_ball_point_multi: idx[%d] is null", r);
+    FPN_REQUIRE(b <= 65535, "query_ball_point_multi: batch %d exceeds 65535", b);
+    long want = ((long)b * m + kQbTargetBlocks - 1) / kQbTargetBlocks;
+    int qpb = (int)std::min<long>(std::max<long>(want, 4), 64);
+    qpb = (qpb + 3) & ~3;
+    const int tile_pts = (std::max(1, std::min(n, kQbTile)) + 1) & ~1;
+    size_t lds = (size_t)tile_pts * 3 * 4 + (size_t)qpb * 2 * 4 * nr;
+    dim3 grid((m + qpb - 1) / qpb, b);
+    hipStream_t st = as_stream(stream);
+    switch (nr) {
+    case 1: hipLaunchKernelGGL(query_ball_multi_kernel<1>, grid, dim3(kQbThreads), lds, st, n, m, qpb, tile_pts, xyz1, xyz2, p); break;
+    case 2: hipLaunchKernelGGL(query_ball_multi_kernel<2>, grid, dim3(kQbThreads), lds, st, n, m, qpb, tile_pts, xyz1, xyz2, p); break;
+    case 3: hipLaunchKernelGGL(query_ball_multi_kernel<3>, grid, dim3(kQbThreads), lds, st, n, m, qpb, tile_pts, xyz1, xyz2, p); break;
+    default: hipLaunchKernelGGL(query_ball_multi_kernel<4>, grid, dim3(kQbThreads), lds, st, n, m, qpb, tile_pts, xyz1, xyz2, p); break;
+    }
+    return check_launch("fpn_query_ball_point_multi");
 }
 
 #define FPN_DISPATCH_LW(lw, KERNEL, ...)                                             \

@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class FpnError(RuntimeError):
@@ -38,6 +38,7 @@ SIGNATURES = {
     "fpn_farthest_point_sample": [_i, _i, _i, _vp, _vp, _vp],
     "fpn_gather_point": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "fpn_query_ball_point": [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    "fpn_query_ball_point_multi": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fpn_group_concat": [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_three_nn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

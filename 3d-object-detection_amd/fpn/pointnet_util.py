@@ -17,7 +17,7 @@ Concatenation orders follow the reference exactly: SSG [xyz, features] (:49), MS
 import torch
 
 from . import _lib, ops, tf_util, variables
-from .tf_ops.tf_grouping import group_point, knn_point, query_ball_point
+from .tf_ops.tf_grouping import group_point, knn_point, query_ball_point, query_ball_point_multi
 from .tf_ops.tf_interpolate import three_nn_interpolate
 from .tf_ops.tf_sampling import farthest_point_sample, gather_point
 
@@ -379,8 +379,10 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
                 and points.shape[2] >= 32 and points.shape[2] % 32 == 0:
             packed = _pack_features(points)       # one table for all scales
         col = 0
+        # all radii in one sweep over the points (the same index tables as one query per radius, :178)
+        balls = query_ball_point_multi(radius_list, nsample_list, xyz, new_xyz, counts=False)
         for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
-            idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            idx = balls[i][0]
             w_i = mlp_list[i][-1]
             if (points is None or use_xyz) and FUSE_SA and \
                     _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx, mlp_list[i],

@@ -29,6 +29,45 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     return idx, cnt
 
 
+def query_ball_point_multi(radius_list, nsample_list, xyz1, xyz2, counts=True):
+    """query_ball_point for several (radius, nsample) pairs over the same xyz1 / xyz2 in one
+    launch (fpn_query_ball_point_multi; the multi-scale set abstraction of
+    models/pointnet_util.py:176-178 asks once per radius): a list of (idx, pts_cnt) pairs,
+    each equal to the single call's.  At most 4 pairs per launch (more are split);
+    counts=False skips the pts_cnt outputs (None in their place)."""
+    import ctypes
+    pairs = [(float(r), int(ns)) for r, ns in zip(radius_list, nsample_list)]
+    if len(pairs) != len(list(radius_list)) or len(pairs) != len(list(nsample_list)) or not pairs:
+        raise ValueError("radius_list and nsample_list must be non-empty and of equal length")
+    for r, ns in pairs:
+        if not r > 0:
+            raise ValueError("QueryBallPoint expects positive radius")
+        if ns <= 0:
+            raise ValueError("QueryBallPoint expects positive nsample")
+    _lib.require_device_tensor("xyz1", xyz1, torch.float32, 3, 3)
+    _lib.require_device_tensor("xyz2", xyz2, torch.float32, 3, 3)
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("QueryBallPoint expects xyz1 and xyz2 with the same batch size")
+    _lib.same_device(xyz1, xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    out = []
+    for lo in range(0, len(pairs), 4):
+        part = pairs[lo:lo + 4]
+        nr = len(part)
+        idx = [torch.empty((b, m, ns), dtype=torch.int32, device=xyz1.device) for _, ns in part]
+        cnt = [torch.empty((b, m), dtype=torch.int32, device=xyz1.device) if counts else None for _ in part]
+        radii = (ctypes.c_float * nr)(*[r for r, _ in part])
+        nsamples = (ctypes.c_int * nr)(*[ns for _, ns in part])
+        idx_p = (ctypes.c_void_p * nr)(*[t.data_ptr() for t in idx])
+        cnt_p = (ctypes.c_void_p * nr)(*[None if t is None else t.data_ptr() for t in cnt])
+        with torch.cuda.device(xyz1.device):
+            _lib.check(_lib.load().fpn_query_ball_point_multi(b, n, m, nr, radii, nsamples, _lib.ptr(xyz1), _lib.ptr(xyz2),
+                                                              idx_p, cnt_p, _lib.stream_of(xyz1)))
+        out += list(zip(idx, cnt))
+    return out
+
+
 def select_top_k(k, dist):
     """k int, dist (B,M,N) float32 -> idx (B,M,N) int32, dist_out (B,M,N) float32;
     the first k columns hold the k smallest of each row.  Reference:

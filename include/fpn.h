@@ -72,6 +72,16 @@ int fpn_gather_point(int b, int n, int m, const float *inp, const int *idx, floa
  */
 int fpn_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
                          const float *xyz2, int *idx, int *pts_cnt, void *stream);
+/*
+ * fpn_query_ball_point for the nr (1..4) radii of a multi-scale set abstraction in one
+ * launch (models/pointnet_util.py:176-178 queries the same xyz / new_xyz once per
+ * radius): radii[r], nsamples[r] (HOST arrays) -> idx[r] (b,m,nsamples[r]) and, where
+ * pts_cnt and pts_cnt[r] are not NULL, pts_cnt[r] (b,m) (HOST arrays of device pointers).
+ * Every output equals the single-radius call's.
+ */
+int fpn_query_ball_point_multi(int b, int n, int m, int nr, const float *radii, const int *nsamples,
+                               const float *xyz1, const float *xyz2, int *const *idx,
+                               int *const *pts_cnt, void *stream);
 
 /*
  * out[i,j,k,:] = points[i,idx[i,j,k],:].  Replaces groupPointLauncher(int b,

@@ -399,3 +399,25 @@ def test_pointset_random_shapes(device):
         # the k smallest squared distances, ascending (ties and rounding aside: compared as values)
         d2 = ((wq[:, :, None, :].astype(np.float64) - x[:, None, :, :]) ** 2).sum(-1)
         np.testing.assert_allclose(val.cpu().numpy(), np.sort(d2, -1)[..., :k], rtol=1e-5, atol=1e-6, err_msg=str(tag))
+
+
+def test_query_ball_point_multi_equals_single_queries(device):
+    """One sweep for several radii (fpn_query_ball_point_multi) gives each radius the index
+    table and the counts of its own fpn_query_ball_point call, bit for bit: full balls (early
+    stop), sparse and empty balls, point counts off the step and tile sizes, five radii (two
+    launches), counts skipped."""
+    from fpn.tf_ops.tf_grouping import query_ball_point, query_ball_point_multi
+    rng = np.random.RandomState(2)
+    for b, n, m in ((3, 2048, 128), (2, 517, 33), (1, 5000, 9), (4, 128, 32)):
+        xyz = rng.random_sample((b, n, 3)).astype(np.float32)
+        new = xyz[:, rng.permutation(n)[:m]] + (rng.random_sample((b, m, 3)).astype(np.float32) - 0.5) * 0.01
+        xyz_d, new_d = torch.from_numpy(xyz).to(device), torch.from_numpy(np.ascontiguousarray(new)).to(device)
+        radii, ns = [0.02, 0.1, 0.2, 0.4, 0.9], [8, 32, 64, 128, 16]
+        many = query_ball_point_multi(radii, ns, xyz_d, new_d)
+        nocnt = query_ball_point_multi(radii[:3], ns[:3], xyz_d, new_d, counts=False)
+        for i, (r, k) in enumerate(zip(radii, ns)):
+            idx, cnt = query_ball_point(r, k, xyz_d, new_d)
+            assert torch.equal(many[i][0], idx), (n, r)
+            assert torch.equal(many[i][1], cnt), (n, r)
+            if i < 3:
+                assert nocnt[i][1] is None and torch.equal(nocnt[i][0], idx)
