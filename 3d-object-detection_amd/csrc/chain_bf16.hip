@@ -112,7 +112,7 @@ __device__ __forceinline__ void opaque(WUnit &u)
 }
 
 struct RingFeed {
-    static constexpr bool kCoop = false;
+    static constexpr int kMode = 0;
     WUnit ring[kRing];
     unsigned lane;
     __device__ __forceinline__ void start(const bf16x8 *__restrict__ ws, unsigned lane_, bf16x8 *)
@@ -138,7 +138,7 @@ struct RingFeed {
 };
 
 struct CoopFeed {
-    static constexpr bool kCoop = true;
+    static constexpr int kMode = 1;
     WUnit frag[4];          // (indexed by stream position mod 4; kFeedRead + 1 of them are live)
     bf16x8 stage[kFeedStage];
     bf16x8 *lds;            // kFeedSlots * kUnitVecs vectors, shared by the workgroup
@@ -200,11 +200,50 @@ struct CoopFeed {
     }
 };
 
+// LdsFeed: the kernel's whole stream lies in LDS (a persistent workgroup copied it there
+// once), followed by copies of its first kLdsAhead units, so that a wave which walks the
+// stream again and again - once per group of points - finds the first units of its next
+// round in its registers when it ends a round.  No memory reads, no barriers: unit x is read
+// from LDS during step x - kLdsAhead.  The stream must hold an even number of units.
+constexpr int kLdsAhead = 2;
+
+struct LdsFeed {
+    static constexpr int kMode = 2;
+    WUnit frag[kLdsAhead];
+    const bf16x8 *lds;      // the stream in LDS
+    const bf16x8 *base;     // the stream in memory: the layers name their units by address there
+    unsigned lane;
+    __device__ __forceinline__ void read_unit(WUnit &u, const bf16x8 *src) const
+    {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) u.w[a][m] = src[(a * 2 + m) * 64 + lane];
+    }
+    __device__ __forceinline__ void start(const bf16x8 *__restrict__ ws, unsigned lane_, bf16x8 *copy)
+    {
+        lane = lane_;
+        lds = copy;
+        base = ws;
+#pragma unroll
+        for (int i = 0; i < kLdsAhead; ++i) read_unit(frag[i], lds + i * kUnitVecs);
+    }
+    template <int PH>
+    __device__ __forceinline__ const WUnit &cur() const { return frag[PH % kLdsAhead]; }
+    template <int PH>
+    __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
+    {
+        read_unit(frag[PH % kLdsAhead], lds + (unit - base) + kLdsAhead * kUnitVecs);
+    }
+    template <int PH>
+    __device__ __forceinline__ void sync() {}
+};
+
 // the workgroup's unit ring in LDS (CoopFeed), none for RingFeed
 template <class Feed>
 __device__ __forceinline__ bf16x8 *feed_ring()
 {
-    if constexpr (Feed::kCoop) {
+    if constexpr (Feed::kMode == 1) {
         __shared__ bf16x8 wring[kFeedSlots * kUnitVecs];
         return wring;
     } else {
@@ -288,13 +327,25 @@ __device__ __forceinline__ void unit_mfma(floatx16 (&acc)[2][NP], const WUnit &u
 // after each MFMA come one memory read (while there are any, NVMEM of them) and up to
 // NVALU vector-ALU instructions - they issue in the 32 cycles the MFMA occupies the pipe;
 // nothing crosses the end of the unit.
-// COOP (CoopFeed): the unit's four weight loads are one load, four LDS reads and one LDS
+// MODE 1 (CoopFeed): the unit's four weight loads are one load, four LDS reads and one LDS
 // write instead, all placed behind the unit's FIRST MFMA: the barrier that may end the
 // unit waits for every LDS operation of the wave, so they get the rest of the unit's MFMAs
 // to complete in.
-template <bool COOP, int NMFMA, int NVMEM, int NVALU>
+template <int MODE, int NMFMA, int NVMEM, int NVALU>
 __device__ __forceinline__ void sched_unit()
 {
+    constexpr bool COOP = MODE == 1;
+    if constexpr (MODE == 2) {      // LdsFeed: the weights and the layer constants are all LDS reads
+        constexpr int PER = (NVMEM + NMFMA - 1) / NMFMA;
+#pragma unroll
+        for (int m = 0; m < NMFMA; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m * PER < NVMEM) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     constexpr int NV = COOP ? NVMEM - 3 : NVMEM;
 #pragma unroll
     for (int m = 0; m < NMFMA; ++m) {
@@ -339,7 +390,7 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
             load_const(csh[0], sh, 32 * (2 * tp) + 4 * h);
             if constexpr (ntile == 2) load_const(csh[1], sh, 32 * (2 * tp + 1) + 4 * h);
         }
-        sched_unit<Feed::kCoop, 2 * ntile * NP, j == NJ - 1 ? 4 + 4 * ntile : 4,
+        sched_unit<Feed::kMode, 2 * ntile * NP, j == NJ - 1 ? 4 + 4 * ntile : 4,
                    (tp > 0 && j < 2) ? (48 * NP + 2 * ntile * NP - 1) / (2 * ntile * NP) : 1>();
         feed.template sync<slot>();
     });
@@ -472,7 +523,7 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
                 rsh[0] = sh[32 * tcur + c];
                 rsh[1] = sh[32 * (tcur + 1) + c];
             }
-            sched_unit<Feed::kCoop, 4 * NP, j == NJ - 1 ? 6 : 4, j < 2 ? (12 * NP + 8 + 4 * NP - 1) / (4 * NP) : 1>();
+            sched_unit<Feed::kMode, 4 * NP, j == NJ - 1 ? 6 : 4, j < 2 ? (12 * NP + 8 + 4 * NP - 1) / (4 * NP) : 1>();
             feed.template sync<slot>();
         });
     }
@@ -938,6 +989,115 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 }
 
 // ---------------------------------------------------------------------------
+// The same module when the first layer reads coordinates (NJF = 0: the stacks of the first
+// multi-scale level, 29 M gathered rows per 1024 frustums through two small layers), as a
+// PERSISTENT kernel.  Launched per group of points, such a wave spent a quarter of its time
+// in MFMAs: before them stood the chain idx -> coordinates -> first layer and the first
+// units of the weight ring, each a trip to memory that a single in-order wave per SIMD
+// cannot hide.  Here a workgroup per CU copies the stream (24-48 KiB) and the shifts into
+// LDS once, and each wave then walks whole balls, 32 NP samples per round:
+//  * weights and shifts come from LDS (LdsFeed), the only memory reads inside a round are
+//    the NEXT round's coordinates and the round after's indices, issued before the round's
+//    first MFMA and not waited for until the next round begins;
+//  * a ball's maxima meet in the wave's own LDS row (no other wave shares a ball), and the
+//    wave stores the finished row itself: no memory atomics, no barrier after the set-up.
+// NSTEP: MFMA steps of the fp32 first layer (two input channels each).
+// ---------------------------------------------------------------------------
+template <int NT1, int NT2, int NT3, int NP, int NSTEP>
+__global__ __launch_bounds__(64 * kWaves, 1) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
+                                                                       unsigned balls_per_wave)
+{
+    constexpr int U2 = ((NT2 + 1) / 2) * NT1, U3 = (NT3 / 2) * NT2, U = U2 + U3, C = 32 * NT3;
+    static_assert(U % kLdsAhead == 0 && NT3 == 4, "unsupported stack");
+    extern __shared__ bf16x8 sa_first_lds[];
+    bf16x8 *wl = sa_first_lds;                                          // U + kLdsAhead units
+    float *lsh2 = reinterpret_cast<float *>(wl + (U + kLdsAhead) * kUnitVecs);
+    float *lsh3 = lsh2 + 32 * NT2;
+    int *lmax = reinterpret_cast<int *>(lsh3 + C) + (threadIdx.x >> 6) * C;
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+
+    for (int i = threadIdx.x; i < U * kUnitVecs; i += 64 * kWaves) wl[i] = p.ws[i];
+    for (int i = threadIdx.x; i < kLdsAhead * kUnitVecs; i += 64 * kWaves) wl[U * kUnitVecs + i] = p.ws[i];
+    for (int i = threadIdx.x; i < 32 * NT2; i += 64 * kWaves) lsh2[i] = p.sh2[i];
+    for (int i = threadIdx.x; i < C; i += 64 * kWaves) lsh3[i] = p.sh3[i];
+    for (int i = lane; i < C; i += 64) lmax[i] = 0;
+    __syncthreads();
+
+    const unsigned gw = __builtin_amdgcn_readfirstlane(logical_block(1) * kWaves + (threadIdx.x >> 6));
+    const unsigned ball0 = gw * balls_per_wave, ball1 = min(balls, ball0 + balls_per_wave);
+    if (ball0 >= ball1) return;
+    const unsigned cpb = p.ns / (32 * NP);          // rounds per ball
+    const unsigned c0 = ball0 * cpb, c1 = ball1 * cpb;
+
+    FirstLayer<NT1, NSTEP> first;
+    first.load(p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
+
+    int pid[NP];
+    float xr[NP][NSTEP], cr[NSTEP];
+    auto load_idx = [&](unsigned c) {
+#pragma unroll
+        for (int g = 0; g < NP; ++g) pid[g] = p.idx[(size_t)c * (32 * NP) + 32 * g + pt];
+    };
+    auto load_x = [&](unsigned c) {         // raw values: nothing here waits for a load it has issued itself
+        const unsigned ball = c / cpb, b = ball / p.m;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) cr[s] = 2 * s + h < 3 ? p.new_xyz[(size_t)ball * 3 + 2 * s + h] : 0.f;
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const size_t q = (size_t)b * p.n + pid[g];
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int k = 2 * s + h;
+                float v = 0.f;
+                if (k < 3) v = p.xyz[q * 3 + k];
+                else if (k < 3 + p.cf) v = p.feat[q * p.cf + k - 3];
+                xr[g][s] = v;
+            }
+        }
+    };
+    load_idx(c0);
+    load_x(c0);
+    load_idx(min(c0 + 1, c1 - 1));
+
+    LdsFeed feed;
+    feed.start(p.ws, lane, wl);
+    const bf16x8 *ws = p.ws;
+    unsigned ball = ball0, in_ball = 0;
+#pragma unroll 1
+    for (unsigned c = c0; c < c1; ++c) {
+        float x[NP][NSTEP];
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) x[g][s] = xr[g][s] - cr[s];
+        load_x(min(c + 1, c1 - 1));
+        load_idx(min(c + 2, c1 - 1));
+        __builtin_amdgcn_sched_barrier(0);
+
+        Act a1[NP][NT1], a2[NP][NT2];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
+        layer_t<NP, NT1, NT2, 0>(a2, a1, ws, lsh2, feed, h);
+        layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws + U2 * kUnitVecs, lsh3, lmax, feed, lane, p.c3);
+
+        if (++in_ball == cpb) {             // the ball is complete: its row leaves, the LDS row starts again from zero
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float *out = p.out + (size_t)ball * p.ldo;
+#pragma unroll
+            for (int ch = lane; ch < C; ch += 64) {
+                const int v = lmax[ch];
+                lmax[ch] = 0;
+                if (ch < p.c3) out[ch] = __int_as_float(v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            in_ball = 0;
+            ++ball;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Per-point head after a feature-propagation step (fp_head_reg_kernel of chain_reg.hip):
 // [interpolated features (32 NJA) | own features (cb <= 32)] -> 128 -> 128 -> 128 -> 2.
 // Stream: layer 1 ((NJA+1)*32 rows: [xa | xb | zeros]), layer 2, layer 3; the inputs are
@@ -1152,6 +1312,40 @@ int launch_sa(const SaParams &p, hipStream_t st)
     return check_launch("fpn_sa_chain_bf16");
 }
 
+// FPN_BF16_SA=launch keeps the per-group kernel for the stacks that read coordinates (a measurement switch)
+inline bool sa_persistent()
+{
+    const char *e = std::getenv("FPN_BF16_SA");
+    return !(e && std::string(e) == "launch");
+}
+
+template <int NT1, int NT2, int NT3>
+int launch_sa_first(const SaParams &p, hipStream_t st)
+{
+    constexpr int U = ((NT2 + 1) / 2) * NT1 + (NT3 / 2) * NT2;
+    constexpr size_t lds = (size_t)(U + kLdsAhead) * kUnitVecs * 16 + (32 * NT2 + 32 * NT3) * 4 + kWaves * 32 * NT3 * 4;
+    static_assert(lds <= 64 * 1024, "the stream does not fit the default LDS limit");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+        return fail(FPN_E_LAUNCH, "sa_chain_bf16: cannot read the device's CU count");
+    const unsigned balls = (unsigned)(p.rows / p.ns);
+    unsigned groups = std::min<unsigned>((unsigned)cus, (balls + kWaves - 1) / kWaves);
+    if (groups >= 8) groups -= groups % 8;          // whole rounds over the XCDs (logical_block)
+    const unsigned per_wave = (balls + groups * kWaves - 1) / (groups * kWaves);
+    const int np = groups_per_wave(p.ns);
+    const dim3 grid(groups), block(64 * kWaves);
+    if (np == 2 && p.cf <= 1)
+        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 2>), grid, block, lds, st, p, balls, per_wave);
+    else if (np == 2)
+        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4>), grid, block, lds, st, p, balls, per_wave);
+    else if (p.cf <= 1)
+        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 2>), grid, block, lds, st, p, balls, per_wave);
+    else
+        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4>), grid, block, lds, st, p, balls, per_wave);
+    return check_launch("fpn_sa_chain_bf16");
+}
+
 }  // namespace
 }  // namespace fpn
 
@@ -1352,6 +1546,11 @@ static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, in
     }
     p.out = out; p.ldo = ldo; p.c3 = c3_valid;
     hipStream_t st = as_stream(stream);
+    if (njf == 0 && sa_persistent() && p.rows < (1L << 31)) {
+        if (t2 == 2) return launch_sa_first<2, 2, 4>(p, st);
+        if (t2 == 3) return launch_sa_first<2, 3, 4>(p, st);
+        return launch_sa_first<2, 4, 4>(p, st);
+    }
     if (njf == 0 && t2 == 2) return launch_sa<0, 2, 2, 4>(p, st);
     if (njf == 0 && t2 == 3) return launch_sa<0, 2, 3, 4>(p, st);
     if (njf == 0) return launch_sa<0, 2, 4, 4>(p, st);

@@ -384,3 +384,42 @@ def test_bf16_packed_features_bit_for_bit(device):
             got[flag] = feat.clone()
         assert torch.equal(got[True], got[False]), kind
         assert got[True].abs().max() > 0
+
+
+def test_bf16_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
+    """Set abstraction in bf16 when the first layer reads coordinates: the persistent kernel
+    (weights resident in LDS, a wave walks whole balls) and the kernel launched per point
+    group (FPN_BF16_SA=launch) give the same bits - three stack shapes, one and two point
+    groups per wave, one to four rounds per ball, 0 / 1 / 4 feature channels beside the
+    coordinates, ball counts that leave waves and whole workgroups without work."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(9)
+    cases = [("msg", 3, 1024, 1, (64, [0.1, 0.2, 0.4], [32, 64, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]])),
+             ("ssg", 2, 512, 0, (5, 0.3, 32, [64, 96, 128])),
+             ("ssg", 1, 512, 4, (3, 0.3, 128, [64, 128, 128])),
+             ("ssg", 5, 700, 1, (129, 0.25, 256, [64, 64, 128])),
+             ("ssg", 40, 256, 0, (128, 0.3, 64, [64, 96, 128]))]
+    for kind, b, n, cf, args in cases:
+        xyz = dev(rng.uniform(0, 1, (b, n, 3)).astype(np.float32), device)
+        pts = dev(rng.standard_normal((b, n, cf)).astype(np.float32), device) if cf else None
+        st = variables.VariableStore(device, seed=6)
+        got = {}
+        for mode in ("persistent", "launch", "persistent"):
+            if mode == "launch":
+                monkeypatch.setenv("FPN_BF16_SA", "launch")
+            else:
+                monkeypatch.delenv("FPN_BF16_SA", raising=False)
+            U.SA_PRECISION = "bf16"
+            try:
+                with variables.use_store(st):
+                    if kind == "msg":
+                        _, feat = U.pointnet_sa_module_msg(xyz, pts, *args, False, None, scope='s')
+                    else:
+                        _, feat, _ = U.pointnet_sa_module(xyz, pts, *args, None, False, False, None, scope='s')
+            finally:
+                U.SA_PRECISION = "fp32"
+            got[mode] = feat.clone()
+        assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
+        assert torch.equal(got["persistent"], got["launch"]), (kind, b, args[0])
+        assert got["persistent"].abs().max() > 0
