@@ -300,6 +300,35 @@ __device__ __forceinline__ floatx16 mfma(const bf16x8 &a, const bf16x8 &b, const
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// The shift can also enter as the accumulator's starting value (the C operand of a tile's
+// first MFMA: register r of every lane is channel (r & 3) + 8 (r >> 2) + 4 h, what a
+// TileConst holds) - then the epilogue is conversion and clamp alone, 16 instructions per
+// tile instead of 24.  The shifts must be there when the tile's first MFMA issues.
+__device__ __forceinline__ floatx16 as_acc(const TileConst &c)
+{
+    floatx16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = comp(c.q[r >> 2], r & 3);
+    return v;
+}
+
+__device__ __forceinline__ void finish0(Act &o, const floatx16 &a)
+{
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        shortx8 bits;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const int r = 8 * s + e;
+            const shortx2 v = __builtin_elementwise_max(
+                __builtin_bit_cast(shortx2, __builtin_convertvector(floatx2{a[r], a[r + 1]}, bf16x2)), shortx2{0, 0});
+            bits[e] = v[0];
+            bits[e + 1] = v[1];
+        }
+        o.m[s] = __builtin_bit_cast(bf16x8, bits);
+    }
+}
+
 // One unit: input tile J of each of the wave's NP point groups against the two output
 // tiles of the pair (4 NP MFMAs, every weight fragment used NP times).  FIRST: the
 // accumulators start from zero (the hardware takes the constant, no register clearing).
@@ -320,6 +349,20 @@ __device__ __forceinline__ void unit_mfma(floatx16 (&acc)[2][NP], const WUnit &u
                 const floatx16 c = (FIRST && m == 0) ? z : acc[t][g];
                 acc[t][g] = T ? mfma(u.w[t][m], in[g][J].m[m], c) : mfma(in[g][J].m[m], u.w[t][m], c);
             }
+}
+
+// ... the same for the first input tile of a pair, the accumulators starting from the shifts
+template <int NTILE, int NP, int NJ>
+__device__ __forceinline__ void unit_mfma_from(floatx16 (&acc)[2][NP], const WUnit &u, const Act (&in)[NP][NJ],
+                                               const TileConst (&init)[2])
+{
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t)
+                acc[t][g] = mfma(u.w[t][m], in[g][0].m[m], m == 0 ? as_acc(init[t]) : acc[t][g]);
 }
 
 // Instruction order inside a unit: the wave issues in order, and a vector-ALU or memory
@@ -399,6 +442,47 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
     for (int g = 0; g < NP; ++g) {
         finish(out[g][2 * NPAIR - 2], acc[last][0][g], csh[0]);
         if constexpr (NT % 2 == 0) finish(out[g][NT - 1], acc[last][1][g], csh[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The transposed layer with the shifts as the accumulators' starting values (made for
+// LdsFeed: the shifts lie in LDS, a pair's are read during the last unit of the pair before;
+// with RingFeed the same arithmetic, the shifts then come from memory).  csh: the
+// shifts of the layer's FIRST pair, read by the caller early enough.
+template <int NP, int NJ, int NT, int R0, class Feed>
+__device__ __forceinline__ void layer_t_from(Act (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
+                                             const float *__restrict__ sh, Feed &feed, int h, TileConst (&csh)[2])
+{
+    static_assert(NJ >= 2 && Feed::kMode != 1, "unsupported layer shape");
+    constexpr int NPAIR = (NT + 1) / 2;
+    constexpr int U = NPAIR * NJ;
+    floatx16 acc[2][2][NP];
+    static_for<0, U>([&](auto I) {
+        constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
+        constexpr int slot = (R0 + S) % kRing;
+        constexpr int ntile = 2 * tp + 1 < NT ? 2 : 1;
+        if constexpr (j == 0) unit_mfma_from<ntile>(acc[set], feed.template cur<slot>(), in, csh);
+        else unit_mfma<false, true, j, ntile>(acc[set], feed.template cur<slot>(), in);
+        feed.template advance<slot>(ws + (size_t)S * kUnitVecs);
+        if constexpr (tp > 0 && j < 2) {
+#pragma unroll
+            for (int g = 0; g < NP; ++g) finish0(out[g][2 * (tp - 1) + j], acc[set ^ 1][j][g]);
+        }
+        constexpr bool more = j == NJ - 1 && tp + 1 < NPAIR;
+        constexpr int nnext = 2 * (tp + 1) + 1 < NT ? 2 : 1;
+        if constexpr (more) {
+            load_const(csh[0], sh, 32 * (2 * tp + 2) + 4 * h);
+            if constexpr (nnext == 2) load_const(csh[1], sh, 32 * (2 * tp + 3) + 4 * h);
+        }
+        sched_unit<Feed::kMode, 2 * ntile * NP, more ? 4 + 4 * nnext : 4,
+                   (tp > 0 && j < 2) ? (32 * NP + 2 * ntile * NP - 1) / (2 * ntile * NP) : 1>();
+    });
+    constexpr int last = (NPAIR - 1) & 1;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        finish0(out[g][2 * NPAIR - 2], acc[last][0][g]);
+        if constexpr (NT % 2 == 0) finish0(out[g][NT - 1], acc[last][1][g]);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -533,20 +617,45 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
     }
 }
 
-// First layer of a stack (K = 3..8 inputs straight from memory) on the fp32 matrix
-// instruction: out[NT] = relu(scale * (W1^T . x^T) + shift) as bf16 operands.  x: the
-// lane's inputs for MFMA steps 0..NSTEP-1, i.e. channels 2s + h of its point (zero beyond
-// the channel count); w1 (K, 32 NT) row-major fp32.
+// First layer of a stack (K = 3..8 inputs straight from memory: coordinates in metres, which
+// one bf16 number would quantise to decimetres): out[NT] = relu(scale * (W1^T . x^T) + shift)
+// as bf16 operands, on the bf16 matrix instruction with SPLIT operands.  Every input and
+// every (scaled) weight is written as the sum of two bf16 numbers, x = xh + xl, w = wh + wl
+// (what is left over is below 2^-16 of the value), and the product taken as
+// xh wh + xl wh + xh wl, exact in the fp32 accumulator: three slots of the instruction's
+// 16-deep contraction per input channel.  KP <= 5 channels fit one MFMA per output tile
+// and 32 points (32 clocks), KP = 8 take two; the fp32 instruction (two channels per
+// 64-clock MFMA, then a multiply-add per result) cost a quarter of a set-abstraction round.
+// Slot q = 16 f + 8 h + e (MFMA f, lane half h, element e) holds channel q % KP, term
+// q / KP (0: xh wh, 1: xl wh, 2: xh wl, above: nothing).  x: all KP channels of the lane's
+// point (both lane halves hold the same point; zero beyond the channel count); w1
+// (K, 32 NT) row-major fp32.
 //
 // The layer's weights and constants are the same for every point group of the wave and
 // depend on nothing the kernel computes: FirstLayer::load is issued BEFORE the kernel
-// gathers its inputs, so that the two memory latencies overlap (a wave per SIMD hides
-// nothing by itself: measured on the set-abstraction kernel, 5.6 k of a wave's 13.2 k
-// cycles went into this layer when its loads sat between the MFMAs).
-template <int NT, int NSTEP>
+// gathers its inputs, so that the two memory latencies overlap.
+template <int NT, int KP>
 struct FirstLayer {
-    float wv[NT][NSTEP];
-    TileConst csc[NT], csh[NT];
+    static constexpr int NMF = (3 * KP + 15) / 16;
+    static_assert(KP >= 3 && KP <= 8, "unsupported channel count");
+    bf16x8 wa[NT][NMF];
+    TileConst csh[NT];
+
+    // the lane's fragment f: element e is slot 16 f + 8 h + e, picked from the channels' high and low parts
+    __device__ static __forceinline__ bf16x8 fragment(const __bf16 (&hi)[KP], const __bf16 (&lo)[KP], int f, int h, bool weights)
+    {
+        bf16x8 v[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int q = 16 * f + 8 * hh + e, ch = q % KP, term = q / KP;
+                // weights: wh, wh, wl; inputs: xh, xl, xh
+                v[hh][e] = term > 2 ? (__bf16)0.f : (term == (weights ? 2 : 1) ? lo[ch] : hi[ch]);
+            }
+        const int4 a = __builtin_bit_cast(int4, v[0]), b = __builtin_bit_cast(int4, v[1]);
+        return __builtin_bit_cast(bf16x8, make_int4(h ? b.x : a.x, h ? b.y : a.y, h ? b.z : a.z, h ? b.w : a.w));
+    }
 
     __device__ __forceinline__ void load(const float *__restrict__ w1, int k_total, const float *__restrict__ sc,
                                          const float *__restrict__ sh, unsigned lane, int h)
@@ -554,42 +663,46 @@ struct FirstLayer {
         const int c = lane & 31;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const float scale = sc[32 * t + c];
+            __bf16 hi[KP], lo[KP];
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                const int k = 2 * s + h;
-                wv[t][s] = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
+            for (int k = 0; k < KP; ++k) {
+                const float w = k < k_total ? w1[k * (32 * NT) + 32 * t + c] * scale : 0.f;
+                hi[k] = (__bf16)w;
+                lo[k] = (__bf16)(w - (float)hi[k]);
             }
-            load_const(csc[t], sc, 32 * t + 4 * h);
+#pragma unroll
+            for (int f = 0; f < NMF; ++f) wa[t][f] = fragment(hi, lo, f, h, true);
             load_const(csh[t], sh, 32 * t + 4 * h);
         }
     }
 
-    // relu(acc * scale + shift) -> bf16: packed multiply-add, packed conversion, the clamp as a
-    // packed 16-bit integer max on the bit patterns (as finish() above)
-    __device__ __forceinline__ void apply(Act (&out)[NT], const float (&x)[NSTEP]) const
+    // all point groups of the wave: the MFMAs first (they are independent), then the epilogues
+    template <int NP>
+    __device__ __forceinline__ void apply(Act (&out)[NP][NT], const float (&x)[NP][KP], int h) const
     {
+        floatx16 acc[NP][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            floatx16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < NP; ++g) {
+            __bf16 hi[KP], lo[KP];
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], x[s], a, 0, 0, 0);
+            for (int k = 0; k < KP; ++k) {
+                hi[k] = (__bf16)x[g][k];
+                lo[k] = (__bf16)(x[g][k] - (float)hi[k]);
+            }
+            bf16x8 xb[NMF];
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                shortx8 bits;
+            for (int f = 0; f < NMF; ++f) xb[f] = fragment(hi, lo, f, h, false);
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const int r = 8 * f + e;
-                    const floatx2 y = __builtin_elementwise_fma(
-                        floatx2{a[r], a[r + 1]}, floatx2{comp(csc[t].q[r >> 2], r & 3), comp(csc[t].q[r >> 2], (r & 3) + 1)},
-                        floatx2{comp(csh[t].q[r >> 2], r & 3), comp(csh[t].q[r >> 2], (r & 3) + 1)});
-                    const shortx2 v = __builtin_elementwise_max(
-                        __builtin_bit_cast(shortx2, __builtin_convertvector(y, bf16x2)), shortx2{0, 0});
-                    bits[e] = v[0];
-                    bits[e + 1] = v[1];
-                }
-                out[t].m[f] = __builtin_bit_cast(bf16x8, bits);
+            for (int t = 0; t < NT; ++t) {
+                acc[g][t] = mfma(wa[t][0], xb[0], as_acc(csh[t]));
+                if constexpr (NMF == 2) acc[g][t] = mfma(wa[t][1], xb[1], acc[g][t]);
             }
         }
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) finish0(out[g][t], acc[g][t]);
         __builtin_amdgcn_sched_barrier(0);
     }
 };
@@ -638,17 +751,16 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     feed.start(p.ws, lane, feed_ring<Feed>());
     Act a1[NP][2], a2[NP][2], a3[NP][2], a4[NP][4];
     {
-        FirstLayer<2, 4> first;
+        FirstLayer<2, 8> first;
         first.load(p.w1, p.cpc, p.sc1, p.sh1, lane, h);
-        float x[NP][4];
+        float x[NP][8];
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
             const float *src = p.pc + (row0 + 32 * g + pt) * p.cpc;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) x[g][s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
+            for (int k = 0; k < 8; ++k) x[g][k] = k < p.cpc ? src[k] : 0.f;
         }
-#pragma unroll
-        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
+        first.apply(a1, x, h);
     }
     constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
     const bf16x8 *ws = p.ws;
@@ -816,20 +928,17 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     feed.start(p.ws, lane, feed_ring<Feed>());
     Act a1[NP][4], a2[NP][4];
     {
-        FirstLayer<4, 2> first;
+        FirstLayer<4, 4> first;
         first.load(p.w1, 3, p.sc1, p.sh1, lane, h);
-        float x[NP][2];
+        float x[NP][4];
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
             const float *src = p.obj + (row0 + 32 * g + pt) * 3;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k = 2 * s + h;
-                x[g][s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
-            }
+            for (int k = 0; k < 3; ++k) x[g][k] = src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f);
+            x[g][3] = 0.f;
         }
-#pragma unroll
-        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
+        first.apply(a1, x, h);
     }
     constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
     const bf16x8 *ws = p.ws;
@@ -872,7 +981,7 @@ struct SaParams {
     int ldo, c3;
 };
 
-template <int NJF, int NT1, int NT2, int NT3, int NP, class Feed = RingFeed>
+template <int NJF, int NT1, int NT2, int NT3, int NP, int KP = 8, class Feed = RingFeed>
 __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_kernel(const SaParams p)
 {
     const unsigned lane = threadIdx.x & 63;
@@ -953,27 +1062,28 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
         else layer_max<NP, NT2, NT3, (U1 + U2) % kRing>(a2, ws, p.sh3, gmax, feed, lane, p.c3);
         FPN_STAMP(4);
     } else {
-        FirstLayer<NT1, 4> first;
+        FirstLayer<NT1, KP> first;
         first.load(p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
-        float x[NP][4];
+        float x[NP][KP];
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
             const float *src = p.xyz + (b * p.n + pid[g]) * 3;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = 2 * s + h;
+            for (int k = 0; k < KP; ++k) {
                 float v = 0.f;
                 if (k < 3) v = src[k] - ctr[k];
                 else if (k < 3 + p.cf) v = p.feat[(b * p.n + pid[g]) * (long)p.cf + k - 3];
-                x[g][s] = v;
+                x[g][k] = v;
             }
         }
         FPN_STAMP(1);
-#pragma unroll
-        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
+        first.apply(a1, x, h);
         FPN_STAMP(2);
         constexpr int U2 = ((NT2 + 1) / 2) * NT1;
-        layer_t<NP, NT1, NT2, 0>(a2, a1, ws, p.sh2, feed, h);
+        TileConst c2[2];        // (the arithmetic of the persistent kernel, bit for bit)
+        load_const(c2[0], p.sh2, 4 * h);
+        load_const(c2[1], p.sh2, 32 + 4 * h);
+        layer_t_from<NP, NT1, NT2, 0>(a2, a1, ws, p.sh2, feed, h, c2);
         FPN_STAMP(3);
         ws += U2 * kUnitVecs;
         if (pool.on) layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane, p.c3);
@@ -1001,10 +1111,10 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 //    first MFMA and not waited for until the next round begins;
 //  * a ball's maxima meet in the wave's own LDS row (no other wave shares a ball), and the
 //    wave stores the finished row itself: no memory atomics, no barrier after the set-up.
-// NSTEP: MFMA steps of the fp32 first layer (two input channels each).
+// KP: input channels of the first layer, padded (4 or 8).
 // ---------------------------------------------------------------------------
-template <int NT1, int NT2, int NT3, int NP, int NSTEP>
-__global__ __launch_bounds__(64 * kWaves, 1) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
+template <int NT1, int NT2, int NT3, int NP, int KP>
+__global__ __launch_bounds__(64 * kWaves, NP == 1 ? 2 : 1) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
                                                                        unsigned balls_per_wave)
 {
     constexpr int U2 = ((NT2 + 1) / 2) * NT1, U3 = (NT3 / 2) * NT2, U = U2 + U3, C = 32 * NT3;
@@ -1030,11 +1140,11 @@ __global__ __launch_bounds__(64 * kWaves, 1) void sa_first_bf16_kernel(const SaP
     const unsigned cpb = p.ns / (32 * NP);          // rounds per ball
     const unsigned c0 = ball0 * cpb, c1 = ball1 * cpb;
 
-    FirstLayer<NT1, NSTEP> first;
+    FirstLayer<NT1, KP> first;
     first.load(p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
 
     int pid[NP];
-    float xr[NP][NSTEP], cr[NSTEP];
+    float xr[NP][KP], cr[3];
     auto load_idx = [&](unsigned c) {
 #pragma unroll
         for (int g = 0; g < NP; ++g) pid[g] = p.idx[(size_t)c * (32 * NP) + 32 * g + pt];
@@ -1042,17 +1152,16 @@ __global__ __launch_bounds__(64 * kWaves, 1) void sa_first_bf16_kernel(const SaP
     auto load_x = [&](unsigned c) {         // raw values: nothing here waits for a load it has issued itself
         const unsigned ball = c / cpb, b = ball / p.m;
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) cr[s] = 2 * s + h < 3 ? p.new_xyz[(size_t)ball * 3 + 2 * s + h] : 0.f;
+        for (int k = 0; k < 3; ++k) cr[k] = p.new_xyz[(size_t)ball * 3 + k];
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
             const size_t q = (size_t)b * p.n + pid[g];
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                const int k = 2 * s + h;
+            for (int k = 0; k < KP; ++k) {
                 float v = 0.f;
                 if (k < 3) v = p.xyz[q * 3 + k];
                 else if (k < 3 + p.cf) v = p.feat[q * p.cf + k - 3];
-                xr[g][s] = v;
+                xr[g][k] = v;
             }
         }
     };
@@ -1064,24 +1173,51 @@ __global__ __launch_bounds__(64 * kWaves, 1) void sa_first_bf16_kernel(const SaP
     feed.start(p.ws, lane, wl);
     const bf16x8 *ws = p.ws;
     unsigned ball = ball0, in_ball = 0;
+#ifdef FPN_SA_STAMPS      // timing-only build: one wave's cycles per phase, averaged over its rounds, into the first output row
+    long long phase[6] = {0, 0, 0, 0, 0, 0}, last = clock64();
+#define FPN_PSTAMP(i) { const long long now = clock64(); phase[i] += now - last; last = now; }
+#else
+#define FPN_PSTAMP(i)
+#endif
 #pragma unroll 1
     for (unsigned c = c0; c < c1; ++c) {
-        float x[NP][NSTEP];
+        float x[NP][KP];
 #pragma unroll
         for (int g = 0; g < NP; ++g)
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) x[g][s] = xr[g][s] - cr[s];
+            for (int k = 0; k < KP; ++k) x[g][k] = k < 3 ? xr[g][k] - cr[k] : xr[g][k];
+#ifndef FPN_SAP_NOGATHER      // (timing-only builds, wrong results: FPN_SAP_NO*)
         load_x(min(c + 1, c1 - 1));
         load_idx(min(c + 2, c1 - 1));
+#endif
+        TileConst c2[2];        // the second layer's first shifts: wanted after the first layer
+        load_const(c2[0], lsh2, 4 * h);
+        load_const(c2[1], lsh2, 32 + 4 * h);
         __builtin_amdgcn_sched_barrier(0);
+        FPN_PSTAMP(1);
 
         Act a1[NP][NT1], a2[NP][NT2];
+#ifndef FPN_SAP_NOFIRST
+        first.apply(a1, x, h);
+#else
 #pragma unroll
-        for (int g = 0; g < NP; ++g) first.apply(a1[g], x[g]);
-        layer_t<NP, NT1, NT2, 0>(a2, a1, ws, lsh2, feed, h);
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) asm volatile("" : "=v"(a1[g][t].m[f]) : "v"(x[g][0]));
+#endif
+        FPN_PSTAMP(2);
+        layer_t_from<NP, NT1, NT2, 0>(a2, a1, ws, lsh2, feed, h, c2);
+        FPN_PSTAMP(3);
         layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws + U2 * kUnitVecs, lsh3, lmax, feed, lane, p.c3);
+        FPN_PSTAMP(4);
 
+#ifdef FPN_SAP_NOFLUSH
+        if (c + 1 == c1) {
+#else
         if (++in_ball == cpb) {             // the ball is complete: its row leaves, the LDS row starts again from zero
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             float *out = p.out + (size_t)ball * p.ldo;
 #pragma unroll
@@ -1094,7 +1230,18 @@ __global__ __launch_bounds__(64 * kWaves, 1) void sa_first_bf16_kernel(const SaP
             in_ball = 0;
             ++ball;
         }
+        FPN_PSTAMP(5);
     }
+#ifdef FPN_SA_STAMPS
+    if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64) {
+        long long t = 0;
+        reinterpret_cast<long long *>(p.out)[0] = 0;
+        for (int i = 1; i < 6; ++i) {
+            t += phase[i] / (c1 - c0);
+            reinterpret_cast<long long *>(p.out)[i] = t;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1305,7 +1452,12 @@ template <int NJF, int NT1, int NT2, int NT3>
 int launch_sa(const SaParams &p, hipStream_t st)
 {
     const int np = groups_per_wave(p.ns);
-    if (np == 2)
+    // (KP: the first layer's padded input channels where it reads coordinates - the same rule as launch_sa_first)
+    if (NJF == 0 && p.cf <= 1 && np == 2)
+        hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 2, 4>), grid_for(p.rows, 2), dim3(64 * kWaves), 0, st, p);
+    else if (NJF == 0 && p.cf <= 1)
+        hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 1, 4>), grid_for(p.rows, 1), dim3(64 * kWaves), 0, st, p);
+    else if (np == 2)
         hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 2>), grid_for(p.rows, 2), dim3(64 * kWaves), 0, st, p);
     else
         hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 1>), grid_for(p.rows, 1), dim3(64 * kWaves), 0, st, p);
@@ -1330,19 +1482,21 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
         cus < 1)
         return fail(FPN_E_LAUNCH, "sa_chain_bf16: cannot read the device's CU count");
     const unsigned balls = (unsigned)(p.rows / p.ns);
-    unsigned groups = std::min<unsigned>((unsigned)cus, (balls + kWaves - 1) / kWaves);
+    const char *e1 = std::getenv("FPN_SA_NP1");
+    const int np = (e1 && e1[0] == '1') ? 1 : groups_per_wave(p.ns);
+    // (one point group per wave leaves registers for two waves per SIMD: two workgroups per CU)
+    unsigned groups = std::min<unsigned>((unsigned)cus * (np == 1 ? 2 : 1), (balls + kWaves - 1) / kWaves);
     if (groups >= 8) groups -= groups % 8;          // whole rounds over the XCDs (logical_block)
     const unsigned per_wave = (balls + groups * kWaves - 1) / (groups * kWaves);
-    const int np = groups_per_wave(p.ns);
     const dim3 grid(groups), block(64 * kWaves);
     if (np == 2 && p.cf <= 1)
-        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 2>), grid, block, lds, st, p, balls, per_wave);
-    else if (np == 2)
         hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4>), grid, block, lds, st, p, balls, per_wave);
+    else if (np == 2)
+        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 8>), grid, block, lds, st, p, balls, per_wave);
     else if (p.cf <= 1)
-        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 2>), grid, block, lds, st, p, balls, per_wave);
-    else
         hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4>), grid, block, lds, st, p, balls, per_wave);
+    else
+        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 8>), grid, block, lds, st, p, balls, per_wave);
     return check_launch("fpn_sa_chain_bf16");
 }
 
