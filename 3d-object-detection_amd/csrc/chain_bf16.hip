@@ -351,6 +351,12 @@ __device__ __forceinline__ void unit_mfma(floatx16 (&acc)[2][NP], const WUnit &u
             }
 }
 
+__device__ __forceinline__ void finish0(floatx16 &o, const floatx16 &a)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = fmaxf(a[r], 0.f);
+}
+
 // ... the same for the first input tile of a pair, the accumulators starting from the shifts
 template <int NTILE, int NP, int NJ>
 __device__ __forceinline__ void unit_mfma_from(floatx16 (&acc)[2][NP], const WUnit &u, const Act (&in)[NP][NJ],
@@ -450,8 +456,8 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
 // LdsFeed: the shifts lie in LDS, a pair's are read during the last unit of the pair before;
 // with RingFeed the same arithmetic, the shifts then come from memory).  csh: the
 // shifts of the layer's FIRST pair, read by the caller early enough.
-template <int NP, int NJ, int NT, int R0, class Feed>
-__device__ __forceinline__ void layer_t_from(Act (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
+template <int NP, int NJ, int NT, int R0, class Out, class Feed>
+__device__ __forceinline__ void layer_t_from(Out (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
                                              const float *__restrict__ sh, Feed &feed, int h, TileConst (&csh)[2])
 {
     static_assert(NJ >= 2 && Feed::kMode != 1, "unsupported layer shape");
@@ -1113,8 +1119,11 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 //    wave stores the finished row itself: no memory atomics, no barrier after the set-up.
 // KP: input channels of the first layer, padded (4 or 8).
 // ---------------------------------------------------------------------------
+#ifndef FPN_SAP_OCC
+#define FPN_SAP_OCC(np) ((np) == 1 ? 2 : 1)
+#endif
 template <int NT1, int NT2, int NT3, int NP, int KP>
-__global__ __launch_bounds__(64 * kWaves, NP == 1 ? 2 : 1) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
+__global__ __launch_bounds__(64 * kWaves, FPN_SAP_OCC(NP)) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
                                                                        unsigned balls_per_wave)
 {
     constexpr int U2 = ((NT2 + 1) / 2) * NT1, U3 = (NT3 / 2) * NT2, U = U2 + U3, C = 32 * NT3;
@@ -1310,11 +1319,18 @@ __global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadP
     __builtin_amdgcn_sched_barrier(0);
     constexpr int U1 = 2 * NJ, U2 = 2 * 4;
     const bf16x8 *ws = p.ws;
-    layer_t<NP, NJ, 4, 0>(a1, in, ws, p.sh1, feed, h);
+    TileConst cs[2];        // (the arithmetic of the persistent kernel, bit for bit)
+    load_const(cs[0], p.sh1, 4 * h);
+    load_const(cs[1], p.sh1, 32 + 4 * h);
+    layer_t_from<NP, NJ, 4, 0>(a1, in, ws, p.sh1, feed, h, cs);
     ws += U1 * kUnitVecs;
-    layer_t<NP, 4, 4, U1 % kRing>(a2, a1, ws, p.sh2, feed, h);
+    load_const(cs[0], p.sh2, 4 * h);
+    load_const(cs[1], p.sh2, 32 + 4 * h);
+    layer_t_from<NP, 4, 4, U1 % kRing>(a2, a1, ws, p.sh2, feed, h, cs);
     ws += U2 * kUnitVecs;
-    layer_t<NP, 4, 4, (U1 + U2) % kRing>(a3, a2, ws, p.sh3, feed, h);
+    load_const(cs[0], p.sh3, 4 * h);
+    load_const(cs[1], p.sh3, 32 + 4 * h);
+    layer_t_from<NP, 4, 4, (U1 + U2) % kRing>(a3, a2, ws, p.sh3, feed, h, cs);
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
         float s0 = 0.f, s1 = 0.f;
@@ -1333,6 +1349,114 @@ __global__ __launch_bounds__(64 * kWaves) void fp_head_bf16_kernel(const FpHeadP
         s1 += __shfl_xor(s1, 32);
         if (h == 0)
             *reinterpret_cast<float2 *>(p.logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + p.b4[0], s1 + p.b4[1]);
+    }
+}
+
+// The same head as a PERSISTENT kernel (as sa_first_bf16_kernel): its stream (26 units) and
+// constants lie in LDS, a wave walks consecutive groups of 32 NP points and reads the next
+// group's inputs - as they lie in memory - while it multiplies this one's.  Launched per
+// group, a wave spent three quarters of its time before and after its MFMAs (first weight
+// units, inputs, the last layer's weights: each a trip to memory).
+template <int NJA, int NP>
+__global__ __launch_bounds__(64 * kWaves, 1) void fp_head_lds_bf16_kernel(const FpHeadParams p, unsigned rounds,
+                                                                          unsigned rounds_per_wave)
+{
+    constexpr int NJ = NJA + 1, U1 = 2 * NJ, U2 = 8, U = U1 + 2 * U2;
+    static_assert(U % kLdsAhead == 0, "unsupported stack");
+    extern __shared__ bf16x8 fp_head_lds[];
+    bf16x8 *wl = fp_head_lds;                                           // U + kLdsAhead units
+    float *lsh = reinterpret_cast<float *>(wl + (U + kLdsAhead) * kUnitVecs);   // shifts of the three layers
+    float *lw4 = lsh + 3 * 128;                                         // (128, 2)
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    for (int i = threadIdx.x; i < U * kUnitVecs; i += 64 * kWaves) wl[i] = p.ws[i];
+    for (int i = threadIdx.x; i < kLdsAhead * kUnitVecs; i += 64 * kWaves) wl[U * kUnitVecs + i] = p.ws[i];
+    for (int i = threadIdx.x; i < 128; i += 64 * kWaves) {
+        lsh[i] = p.sh1[i];
+        lsh[128 + i] = p.sh2[i];
+        lsh[256 + i] = p.sh3[i];
+        lw4[i] = p.w4[i];
+        lw4[128 + i] = p.w4[128 + i];
+    }
+    __syncthreads();
+    const unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (threadIdx.x >> 6));
+    const unsigned r0 = gw * rounds_per_wave, r1 = min(rounds, r0 + rounds_per_wave);
+    if (r0 >= r1) return;
+    const float b40 = p.b4[0], b41 = p.b4[1];
+
+    // a group's inputs as they lie in memory: 16 x 8 bytes of its interpolated row (bf16) per
+    // lane, and the lane's part of the (at most 8) own channels
+    constexpr int NQ = 4 * NJA;
+    bf16x4 ra[NP][NQ];
+    float rb[NP][4];
+    auto load_in = [&](unsigned r) {
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const size_t row = (size_t)r * (32 * NP) + 32 * g + pt;
+            const bf16x4 *xa = reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(p.xa) + row * (32 * NJA));
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) ra[g][i] = xa[2 * i + h];
+            if (p.cb > 0) {                 // (uniform)
+                const float *xb = p.xb + row * (size_t)p.cb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[g][i] = xb[min(4 * h + i, p.cb - 1)];
+            }
+        }
+    };
+    load_in(r0);
+
+    LdsFeed feed;
+    feed.start(p.ws, lane, wl);
+    const bf16x8 *ws = p.ws;
+#pragma unroll 1
+    for (unsigned r = r0; r < r1; ++r) {
+        Act in[NP][NJ];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int t = i >> 2, q = i & 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) in[g][t].m[q >> 1][4 * (q & 1) + e] = ra[g][i][e];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)        // channels 4 h + k of the last tile, k < 4; the rest is padding
+                in[g][NJA].m[k >> 3][k & 7] = (__bf16)((k < 4 && 4 * h + k < p.cb) ? rb[g][k & 3] : 0.f);
+        }
+        load_in(min(r + 1, r1 - 1));
+        TileConst cs[2], cn[2];
+        load_const(cs[0], lsh, 4 * h);
+        load_const(cs[1], lsh, 32 + 4 * h);
+        load_const(cn[0], lsh + 128, 4 * h);
+        load_const(cn[1], lsh + 128, 32 + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
+
+        Act a1[NP][4], a2[NP][4];
+        floatx16 a3[NP][4];
+        layer_t_from<NP, NJ, 4, 0>(a1, in, ws, lsh, feed, h, cs);
+        load_const(cs[0], lsh + 256, 4 * h);
+        load_const(cs[1], lsh + 256, 32 + 4 * h);
+        layer_t_from<NP, 4, 4, U1 % kRing>(a2, a1, ws + U1 * kUnitVecs, lsh + 128, feed, h, cn);
+        layer_t_from<NP, 4, 4, (U1 + U2) % kRing>(a3, a2, ws + (U1 + U2) * kUnitVecs, lsh + 256, feed, h, cs);
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 *w = reinterpret_cast<const float4 *>(lw4 + (32 * j + 8 * q + 4 * h) * 2);
+                    const float4 wa = w[0], wb = w[1];
+                    s0 = fmaf(a3[g][j][4 * q + 0], wa.x, s0); s1 = fmaf(a3[g][j][4 * q + 0], wa.y, s1);
+                    s0 = fmaf(a3[g][j][4 * q + 1], wa.z, s0); s1 = fmaf(a3[g][j][4 * q + 1], wa.w, s1);
+                    s0 = fmaf(a3[g][j][4 * q + 2], wb.x, s0); s1 = fmaf(a3[g][j][4 * q + 2], wb.y, s1);
+                    s0 = fmaf(a3[g][j][4 * q + 3], wb.z, s0); s1 = fmaf(a3[g][j][4 * q + 3], wb.w, s1);
+                }
+            s0 += __shfl_xor(s0, 32);
+            s1 += __shfl_xor(s1, 32);
+            if (h == 0)
+                *reinterpret_cast<float2 *>(p.logits + ((size_t)r * (32 * NP) + 32 * g + pt) * 2) = make_float2(s0 + b40, s1 + b41);
+        }
     }
 }
 
@@ -1485,7 +1609,7 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
     const char *e1 = std::getenv("FPN_SA_NP1");
     const int np = (e1 && e1[0] == '1') ? 1 : groups_per_wave(p.ns);
     // (one point group per wave leaves registers for two waves per SIMD: two workgroups per CU)
-    unsigned groups = std::min<unsigned>((unsigned)cus * (np == 1 ? 2 : 1), (balls + kWaves - 1) / kWaves);
+    unsigned groups = std::min<unsigned>((unsigned)cus * FPN_SAP_OCC(np), (balls + kWaves - 1) / kWaves);
     if (groups >= 8) groups -= groups % 8;          // whole rounds over the XCDs (logical_block)
     const unsigned per_wave = (balls + groups * kWaves - 1) / (groups * kWaves);
     const dim3 grid(groups), block(64 * kWaves);
@@ -1636,7 +1760,28 @@ static int fp_head_chain_bf16(long rows, int ca, int cb, const void *xa_any, int
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh1 = consts[0]; p.sh2 = consts[1]; p.sh3 = consts[2]; p.w4 = consts[3]; p.b4 = consts[4];
     p.logits = logits;
-    if (groups_per_wave((int)(rows % 64 == 0 ? 64 : 32)) == 2)
+    const int np = groups_per_wave((int)(rows % 64 == 0 ? 64 : 32));
+    if (sa_persistent() && xa_bf16 && cb <= 8 && rows / (32 * np) < (1L << 31)) {
+        constexpr int U = 2 * 5 + 8 + 8;
+        constexpr size_t lds = (size_t)(U + kLdsAhead) * kUnitVecs * 16 + (3 * 128 + 256) * 4;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            return fail(FPN_E_LAUNCH, "fp_head_chain_bf16: cannot read the device's CU count");
+        const unsigned rounds = (unsigned)(rows / (32 * np));
+        const unsigned groups = std::min<unsigned>((unsigned)cus, (rounds + kWaves - 1) / kWaves);
+        const unsigned per_wave = (rounds + groups * kWaves - 1) / (groups * kWaves);
+        const void *fn = np == 2 ? reinterpret_cast<const void *>(&fp_head_lds_bf16_kernel<4, 2>)
+                                 : reinterpret_cast<const void *>(&fp_head_lds_bf16_kernel<4, 1>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FPN_E_LAUNCH, "fp_head_chain_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
+        if (np == 2)
+            hipLaunchKernelGGL((fp_head_lds_bf16_kernel<4, 2>), dim3(groups), dim3(64 * kWaves), lds, as_stream(stream), p, rounds, per_wave);
+        else
+            hipLaunchKernelGGL((fp_head_lds_bf16_kernel<4, 1>), dim3(groups), dim3(64 * kWaves), lds, as_stream(stream), p, rounds, per_wave);
+        return check_launch("fpn_fp_head_chain_bf16");
+    }
+    if (np == 2)
         hipLaunchKernelGGL((fp_head_bf16_kernel<4, 2>), grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
     else
         hipLaunchKernelGGL((fp_head_bf16_kernel<4, 1>), grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);

@@ -423,3 +423,37 @@ def test_bf16_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
         assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
         assert torch.equal(got["persistent"], got["launch"]), (kind, b, args[0])
         assert got["persistent"].abs().max() > 0
+
+
+@pytest.mark.parametrize("b,n,cb", [(3, 224, 4), (1, 96, 0), (5, 2048, 7), (2, 160, 8), (300, 64, 1)])
+def test_bf16_persistent_head_bit_for_bit(device, monkeypatch, b, n, cb):
+    """Feature propagation + per-point head in bf16: the persistent kernel (stream in LDS, a
+    wave walks consecutive point groups with the next group's inputs in flight) and the kernel
+    launched per group (FPN_BF16_SA=launch) give the same logits bit for bit - row counts that
+    are odd multiples of 32 (one group per wave), that leave waves without work, that give
+    the waves unequal shares; 0 to 8 own channels."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(b + cb)
+    m = 48
+    xyz1 = dev(rng.uniform(0, 1, (b, n, 3)).astype(np.float32), device)
+    xyz2 = xyz1[:, :m].contiguous()
+    p1 = dev(rng.standard_normal((b, n, cb)).astype(np.float32), device) if cb else None
+    p2 = dev(rng.standard_normal((b, m, 128)).astype(np.float32), device)
+    st = variables.VariableStore(device, seed=4)
+    got = {}
+    for mode in ("persistent", "launch", "persistent"):
+        if mode == "launch":
+            monkeypatch.setenv("FPN_BF16_SA", "launch")
+        else:
+            monkeypatch.delenv("FPN_BF16_SA", raising=False)
+        U.SA_PRECISION = "bf16"
+        try:
+            with variables.use_store(st):
+                got[mode] = U.pointnet_fp_module_with_head(xyz1, xyz2, p1, p2, [128, 128], 128, 2, False, None, scope='fa',
+                                                           head_scope='h1', out_scope='h2').clone()
+        finally:
+            U.SA_PRECISION = "fp32"
+    assert len(st.__dict__.get("_fp_head_cache", {})) == 1, "fused kernel not taken"
+    assert torch.equal(got["persistent"], got["launch"])
+    assert got["persistent"].abs().max() > 0
