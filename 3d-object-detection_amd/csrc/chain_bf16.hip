@@ -2,9 +2,10 @@
 // the same chains as chain_reg.hip - a wave carries its points through consecutive
 // shared-MLP layers, every layer computed transposed so that its result is already the
 // next layer's operand - with bf16 weights and bf16 activations between the layers and
-// fp32 accumulation.  Kept in fp32: the first layer of every stack (its inputs are
-// coordinates in metres, which bf16's 8 bits of mantissa would quantise to decimetres),
-// the batch-norm shifts, the maxima over points and the final 128 -> 2 layer.
+// fp32 accumulation.  The first layer of every stack reads coordinates in metres, which
+// bf16's 8 bits of mantissa would quantise to decimetres: it multiplies split operands
+// (FirstLayer below).  Kept in fp32: the batch-norm shifts, the maxima over points and the
+// final 128 -> 2 layer.
 //
 // Operand shapes.  One MFMA contracts over 16 channels; lane (p = lane & 31,
 // h = lane >> 5) supplies 8 of them.  A 32 x 32 fp32 result tile (lane = point p,
@@ -633,7 +634,8 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
 // and 32 points (32 clocks), KP = 8 take two; the fp32 instruction (two channels per
 // 64-clock MFMA, then a multiply-add per result) cost a quarter of a set-abstraction round.
 // Slot q = 16 f + 8 h + e (MFMA f, lane half h, element e) holds channel q % KP, term
-// q / KP (0: xh wh, 1: xl wh, 2: xh wl, above: nothing).  x: all KP channels of the lane's
+// q / KP (0: xh wh, 1: xl wh, 2: xh wl, above: nothing); two more slots hold the shift, split
+// the same way, against inputs of 1 - no constant to add afterwards.  x: all KP channels of the lane's
 // point (both lane halves hold the same point; zero beyond the channel count); w1
 // (K, 32 NT) row-major fp32.
 //
@@ -642,13 +644,15 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
 // gathers its inputs, so that the two memory latencies overlap.
 template <int NT, int KP>
 struct FirstLayer {
-    static constexpr int NMF = (3 * KP + 15) / 16;
-    static_assert(KP >= 3 && KP <= 8, "unsupported channel count");
+    static constexpr int NMF = (3 * KP + 2 + 15) / 16;
+    static_assert(KP >= 3 && KP <= 8 && NMF <= 2, "unsupported channel count");
     bf16x8 wa[NT][NMF];
-    TileConst csh[NT];
 
-    // the lane's fragment f: element e is slot 16 f + 8 h + e, picked from the channels' high and low parts
-    __device__ static __forceinline__ bf16x8 fragment(const __bf16 (&hi)[KP], const __bf16 (&lo)[KP], int f, int h, bool weights)
+    // the lane's fragment f: element e is slot 16 f + 8 h + e, picked from the channels' high and
+    // low parts; slots 3 KP and 3 KP + 1 carry the shift (one0 = its high part, one1 = its low
+    // part) against inputs of 1
+    __device__ static __forceinline__ bf16x8 fragment(const __bf16 (&hi)[KP], const __bf16 (&lo)[KP], __bf16 one0, __bf16 one1,
+                                                      int f, int h, bool weights)
     {
         bf16x8 v[2];
 #pragma unroll
@@ -657,7 +661,8 @@ struct FirstLayer {
             for (int e = 0; e < 8; ++e) {
                 const int q = 16 * f + 8 * hh + e, ch = q % KP, term = q / KP;
                 // weights: wh, wh, wl; inputs: xh, xl, xh
-                v[hh][e] = term > 2 ? (__bf16)0.f : (term == (weights ? 2 : 1) ? lo[ch] : hi[ch]);
+                v[hh][e] = q == 3 * KP ? one0 : q == 3 * KP + 1 ? one1 : term > 2 ? (__bf16)0.f
+                                                                 : (term == (weights ? 2 : 1) ? lo[ch] : hi[ch]);
             }
         const int4 a = __builtin_bit_cast(int4, v[0]), b = __builtin_bit_cast(int4, v[1]);
         return __builtin_bit_cast(bf16x8, make_int4(h ? b.x : a.x, h ? b.y : a.y, h ? b.z : a.z, h ? b.w : a.w));
@@ -669,7 +674,7 @@ struct FirstLayer {
         const int c = lane & 31;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float scale = sc[32 * t + c];
+            const float scale = sc[32 * t + c], shift = sh[32 * t + c];
             __bf16 hi[KP], lo[KP];
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
@@ -677,9 +682,9 @@ struct FirstLayer {
                 hi[k] = (__bf16)w;
                 lo[k] = (__bf16)(w - (float)hi[k]);
             }
+            const __bf16 s0 = (__bf16)shift, s1 = (__bf16)(shift - (float)s0);
 #pragma unroll
-            for (int f = 0; f < NMF; ++f) wa[t][f] = fragment(hi, lo, f, h, true);
-            load_const(csh[t], sh, 32 * t + 4 * h);
+            for (int f = 0; f < NMF; ++f) wa[t][f] = fragment(hi, lo, s0, s1, f, h, true);
         }
     }
 
@@ -687,6 +692,7 @@ struct FirstLayer {
     template <int NP>
     __device__ __forceinline__ void apply(Act (&out)[NP][NT], const float (&x)[NP][KP], int h) const
     {
+        const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         floatx16 acc[NP][NT];
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
@@ -698,10 +704,10 @@ struct FirstLayer {
             }
             bf16x8 xb[NMF];
 #pragma unroll
-            for (int f = 0; f < NMF; ++f) xb[f] = fragment(hi, lo, f, h, false);
+            for (int f = 0; f < NMF; ++f) xb[f] = fragment(hi, lo, (__bf16)1.f, (__bf16)1.f, f, h, false);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[g][t] = mfma(wa[t][0], xb[0], as_acc(csh[t]));
+                acc[g][t] = mfma(wa[t][0], xb[0], z);
                 if constexpr (NMF == 2) acc[g][t] = mfma(wa[t][1], xb[1], acc[g][t]);
             }
         }
@@ -1576,12 +1582,20 @@ template <int NJF, int NT1, int NT2, int NT3>
 int launch_sa(const SaParams &p, hipStream_t st)
 {
     const int np = groups_per_wave(p.ns);
+    // (the workgroup's LDS ring, CoopFeed, was measured for the stacks over point features as well: 1.08 -> 1.20 ms
+    // for the 352-128-128-256 pair of launches, 0.35 -> 0.39 for 160-128-128-256: with two point groups per wave
+    // the weight reads are not what these kernels wait for, and the ring's barriers cost more than they save)
     // (KP: the first layer's padded input channels where it reads coordinates - the same rule as launch_sa_first)
-    if (NJF == 0 && p.cf <= 1 && np == 2)
-        hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 2, 4>), grid_for(p.rows, 2), dim3(64 * kWaves), 0, st, p);
-    else if (NJF == 0 && p.cf <= 1)
-        hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 1, 4>), grid_for(p.rows, 1), dim3(64 * kWaves), 0, st, p);
-    else if (np == 2)
+    if constexpr (NJF == 0) {
+        if (p.cf <= 1) {
+            if (np == 2)
+                hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 2, 4>), grid_for(p.rows, 2), dim3(64 * kWaves), 0, st, p);
+            else
+                hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 1, 4>), grid_for(p.rows, 1), dim3(64 * kWaves), 0, st, p);
+            return check_launch("fpn_sa_chain_bf16");
+        }
+    }
+    if (np == 2)
         hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 2>), grid_for(p.rows, 2), dim3(64 * kWaves), 0, st, p);
     else
         hipLaunchKernelGGL((sa_chain_bf16_kernel<NJF, NT1, NT2, NT3, 1>), grid_for(p.rows, 1), dim3(64 * kWaves), 0, st, p);
@@ -1606,9 +1620,9 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
         cus < 1)
         return fail(FPN_E_LAUNCH, "sa_chain_bf16: cannot read the device's CU count");
     const unsigned balls = (unsigned)(p.rows / p.ns);
-    const char *e1 = std::getenv("FPN_SA_NP1");
-    const int np = (e1 && e1[0] == '1') ? 1 : groups_per_wave(p.ns);
-    // (one point group per wave leaves registers for two waves per SIMD: two workgroups per CU)
+    const int np = groups_per_wave(p.ns);
+    // (one point group per wave leaves registers for two waves per SIMD: two workgroups per CU; measured for
+    // balls of 64 and 128 samples too: the same times as two groups per wave at one wave per SIMD)
     unsigned groups = std::min<unsigned>((unsigned)cus * FPN_SAP_OCC(np), (balls + kWaves - 1) / kWaves);
     if (groups >= 8) groups -= groups % 8;          // whole rounds over the XCDs (logical_block)
     const unsigned per_wave = (balls + groups * kWaves - 1) / (groups * kWaves);
