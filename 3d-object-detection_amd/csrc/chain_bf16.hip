@@ -1052,14 +1052,20 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
                         in[g][t].m[q >> 1][4 * (q & 1) + 3] = (__bf16)v.w;
                     }
             }
-            // channels 0..2 of the last tile: elements 0..2 of fragment 0 in the lower lane half
+            // the coordinates ride in the last tile as two bf16 numbers each (one alone would quantise
+            // metres to decimetres): the high parts in channels 0..2 (elements 0..2 of fragment 0 in the
+            // lower lane half), what they leave over in channels 4..6 (the same elements in the upper
+            // half), against the same three weight rows
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) in[g][NJF].m[s][e] = (__bf16)0.f;
-            in[g][NJF].m[0][0] = (__bf16)(h == 0 ? src[0] - ctr[0] : 0.f);
-            in[g][NJF].m[0][1] = (__bf16)(h == 0 ? src[1] - ctr[1] : 0.f);
-            in[g][NJF].m[0][2] = (__bf16)(h == 0 ? src[2] - ctr[2] : 0.f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = src[k] - ctr[k];
+                const __bf16 hi = (__bf16)d;
+                in[g][NJF].m[0][k] = h == 0 ? hi : (__bf16)(d - (float)hi);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         FPN_STAMP(1);
@@ -1827,6 +1833,16 @@ int fpn_sa_pack_features_bf16(long points, int cf, const float *feat, void *pack
     return check_launch("fpn_sa_pack_features_bf16");
 }
 
+int fpn_sa_chain_bf16_supported(int cf, int c1, int c2, int c3)
+{
+    // two group-all stacks (one ball per frustum: 32 points x 640 / 256 features) exist in bf16 only
+    if ((cf == 640 && c1 == 128 && c2 == 256 && c3 == 1024) || (cf == 256 && c1 == 256 && c2 == 256 && c3 == 512)) return 1;
+    // the bf16 weight streams pair output tiles: widths are multiples of 64, except the middle layer of the
+    // 64-96-128 stack, whose stream holds the layer padded to 128 columns and the last layer with 96 rows
+    if (c2 % 64 != 0 && !(cf < 32 && c1 == 64 && c2 == 96 && c3 == 128)) return 0;
+    return fpn_sa_chain_supported(cf, c1, c2, c3);
+}
+
 static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                          const float *new_xyz, const float *feat, const void *feat_packed, const int *idx,
                          const void *wstream, const float *const *consts, float *out, int ldo, int c3_valid,
@@ -1836,9 +1852,7 @@ static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, in
     FPN_REQUIRE(ns % 32 == 0, "sa_chain_bf16: samples per ball (%d) must be a multiple of 32", ns);
     FPN_REQUIRE(c3_valid >= 64 && c3_valid % 64 == 0 && c3_valid <= c3 && ldo >= c3_valid,
                 "sa_chain_bf16: bad output width %d (c3 %d, ld %d)", c3_valid, c3, ldo);
-    // (the bf16 weight streams pair output tiles: widths are multiples of 64, except the middle layer of the
-    // 64-96-128 stack, whose stream holds the layer padded to 128 columns and the last layer with 96 rows)
-    if ((c2 % 64 != 0 && !(cf < 32 && c1 == 64 && c2 == 96 && c3 == 128)) || !fpn_sa_chain_supported(cf, c1, c2, c3))
+    if (!fpn_sa_chain_bf16_supported(cf, c1, c2, c3))
         return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
     if (b == 0) return FPN_OK;
     FPN_REQUIRE(xyz && new_xyz && idx && wstream && consts && out && (cf == 0 || feat || feat_packed), "sa_chain_bf16: null pointer");
@@ -1869,6 +1883,8 @@ static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, in
     if (njf == 0) return launch_sa<0, 2, 4, 4>(p, st);
     if (njf == 10 && t1 == 2) return launch_sa<10, 2, 2, 4>(p, st);
     if (njf == 10) return launch_sa<10, 4, 4, 8>(p, st);
+    if (njf == 20) return launch_sa<20, 4, 8, 32>(p, st);
+    if (njf == 8) return launch_sa<8, 8, 8, 16>(p, st);
     return launch_sa<4, 4, 4, 8>(p, st);
 }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class FpnError(RuntimeError):
@@ -55,6 +55,7 @@ SIGNATURES = {
     "fpn_max_pool_rows": [_l, _i, _i, _vp, _i, _vp, _i, _vp],
     "fpn_tile_weights_reg_f32": [_i, _i, _i, _vp, _vp, _vp],
     "fpn_sa_chain_supported": [_i, _i, _i, _i],
+    "fpn_sa_chain_bf16_supported": [_i, _i, _i, _i],
     "fpn_sa_chain_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],

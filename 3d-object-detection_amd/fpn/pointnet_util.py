@@ -75,18 +75,19 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
 _GROUP_ALL_CONSTANTS = {}
 
 
-def _group_all_constants(b, n, device):
+def _group_all_constants(b, n, device, dense=False):
     """The centroid (0,0,0) and the index table 0..n-1 of sample_and_group_all: the same
     for every call of a shape, so they are made once.  The index table is handed out as
-    an expanded (stride-0) view, which torch refuses to write in place; the caller gets its
+    an expanded (stride-0) view, which torch refuses to write in place (`dense`: as a table
+    with a row per frustum, which a kernel can read; do not write it); the caller gets its
     own copy of the centroid."""
-    key = (b, n, device)
+    key = (b, n, device, dense)
     hit = _GROUP_ALL_CONSTANTS.get(key)
     if hit is None:
         if len(_GROUP_ALL_CONSTANTS) >= 64:
             _GROUP_ALL_CONSTANTS.clear()
-        hit = (torch.zeros((b, 1, 3), dtype=torch.float32, device=device),
-               torch.arange(n, dtype=torch.int32, device=device).reshape(1, 1, n).expand(b, 1, n))
+        idx = torch.arange(n, dtype=torch.int32, device=device).reshape(1, 1, n).expand(b, 1, n)
+        hit = (torch.zeros((b, 1, 3), dtype=torch.float32, device=device), idx.contiguous() if dense else idx)
         _GROUP_ALL_CONSTANTS[key] = hit
     return hit
 
@@ -136,8 +137,8 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     pad = None
     for mid in (32, 64):
         cand = (_round_up(widths[0], 64), _round_up(widths[1], mid), _round_up(widths[2], 128))
-        if _lib.load().fpn_sa_chain_supported(cf, *cand) and \
-                (SA_PRECISION != "bf16" or mid == 64 or (cf < 32 and cand == (64, 96, 128))):
+        supported = _lib.load().fpn_sa_chain_bf16_supported if SA_PRECISION == "bf16" else _lib.load().fpn_sa_chain_supported
+        if supported(cf, *cand):
             pad = cand
             break
     if pad is None:
@@ -175,7 +176,9 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
         # one bf16 weight stream (scales folded into the columns); fp32 first layer when
         # it reads the coordinates and features straight from memory (cf < 32)
         if cf >= 32:
-            w1p = padded(torch.cat([feat_rows, xyz_rows], 0), s1, h1, cf + 32, pad[0])[0]
+            # the kernel feeds every coordinate as two bf16 numbers (rows cf..cf+2 and cf+4..cf+6): the same weights twice
+            w1p = padded(torch.cat([feat_rows, xyz_rows, torch.zeros_like(xyz_rows[:1]), xyz_rows], 0), s1, h1, cf + 32,
+                         pad[0])[0]
             stream = ops.chain_stream_bf16([(w1p, s1p), (w2p, s2p), (w3p, s3p)])
             tensors = [h1p, h2p, h3p]
         else:
@@ -312,6 +315,15 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             if _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx.contiguous(), mlp,
                          'conv%d', bn, pooled, xyz_first=True):
                 return new_xyz, pooled.reshape(xyz.shape[0], npoint, pooled.shape[-1]), idx
+        if group_all and SA_PRECISION == "bf16" and FUSE_SA and points is not None and use_xyz \
+                and pooling == 'max' and mlp2 is None and len(mlp) == 3:
+            # group-all (:62-84, :108-109) as ONE ball per frustum of the fused kernel: every point in index order,
+            # centre at the origin (the coordinates are not translated)
+            b, n, _ = xyz.shape
+            new_xyz, table = _group_all_constants(b, n, xyz.device, dense=True)
+            pooled = torch.empty((b, mlp[-1]), dtype=torch.float32, device=xyz.device)
+            if _sa_chain(xyz.contiguous(), new_xyz, points.contiguous(), table, mlp, 'conv%d', bn, pooled, xyz_first=True):
+                return new_xyz.clone(), pooled.reshape(b, 1, pooled.shape[-1]), _group_all_constants(b, n, xyz.device)[1]
         if group_all and SA_PRECISION == "bf16" and FUSE_SA and points is not None and use_xyz \
                 and pooling == 'max' and len(mlp) >= 2:
             # group-all in bf16: the first layer's input is [xyz | features] (:77); the three coordinate

@@ -478,8 +478,15 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
  *   cf < 32 : stream: layer 2, layer 3; consts {w1 (3+cf,c1) fp32, scale1, shift1,
  *             shift2, shift3}; with c2 = 96 (c1 = 64, c3 = 128) the stream holds layer 2
  *             packed as (64,128) - columns 96..127 zero - and layer 3 as (96,128);
- *   cf >= 32: stream: layer 1 (rows [features, dx,dy,dz, 29 zero rows]), layer 2,
- *             layer 3; consts {shift1, shift2, shift3}. */
+ *   cf >= 32: stream: layer 1 (rows [features, dx,dy,dz, a zero row, dx,dy,dz again, 25
+ *             zero rows]: the kernel feeds each coordinate as two bf16 numbers, the
+ *             second what the first leaves over), layer 2, layer 3; consts {shift1,
+ *             shift2, shift3}.
+ * fpn_sa_chain_bf16_supported: the shapes of fpn_sa_chain_supported whose widths suit the
+ * stream, plus two group-all stacks (models/pointnet_util.py:62-84, :108-109: one ball of
+ * all 32 points per frustum - idx = 0..31, new_xyz = 0 - over 640 features through
+ * 128-256-1024 and over 256 features through 256-256-512). */
+int fpn_sa_chain_bf16_supported(int cf, int c1, int c2, int c3);
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                       const float *new_xyz, const float *feat, const int *idx, const void *wstream,
                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream);

@@ -134,6 +134,9 @@ def test_bf16_set_abstraction_within_stated_bound(device):
         ("ssg", xyz_big, None, (64, 0.2, 64, [64, 64, 128])),
         ("ssg", xyz_big, None, (64, 0.3, 32, [64, 96, 128])),       # three-tile middle layer, one point group per wave
         ("ssg", xyz_small, rng.standard_normal((b, 128, 128)).astype(np.float32), (32, 0.4, 64, [128, 128, 256])),
+        # group-all as one ball per frustum: coordinates in metres, not translated
+        ("all", xyz_small[:, :32] * 30 + 5, rng.standard_normal((b, 32, 640)).astype(np.float32), [128, 256, 1024]),
+        ("all", xyz_small[:, :32] * 30 - 20, rng.standard_normal((b, 32, 256)).astype(np.float32), [256, 256, 512]),
     ]
     for kind, xyz, pts, args in cases:
         st = variables.VariableStore(device, seed=5)
@@ -145,6 +148,11 @@ def test_bf16_set_abstraction_within_stated_bound(device):
                     p = None if pts is None else dev(pts, device)
                     if kind == "msg":
                         _, feat = U.pointnet_sa_module_msg(dev(xyz, device), p, *args, False, None, scope='s')
+                    elif kind == "all":
+                        nx, feat, ix = U.pointnet_sa_module(dev(xyz.astype(np.float32), device), p, None, None, None, args, None,
+                                                            True, False, None, scope='s')
+                        assert nx.shape == (b, 1, 3) and float(nx.abs().max()) == 0.0
+                        assert torch.equal(ix[0, 0].cpu(), torch.arange(32, dtype=torch.int32)) and ix.shape == (b, 1, 32)
                     else:
                         _, feat, _ = U.pointnet_sa_module(dev(xyz, device), p, *args, None, False, False, None, scope='s')
             finally:
@@ -157,6 +165,7 @@ def test_bf16_set_abstraction_within_stated_bound(device):
         assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
         err = scaled_err(outs["bf16"], outs["fp32"])
         assert 1e-6 < err <= BF16_RTOL, (kind, args[0], err)
+        print(kind, args if kind == "all" else args[0], "bf16 vs fp32: %.4f" % err)
 
 
 def test_bf16_flipout_streams_exact(device):
