@@ -688,9 +688,12 @@ struct FirstLayer {
         }
     }
 
-    // all point groups of the wave: the MFMAs first (they are independent), then the epilogues
+    // all point groups of the wave: the MFMAs first (they are independent), then the epilogues.
+    // init: NULL, or per group and tile what other inputs of the layer have contributed already
+    // (scaled like the weights; register r of a lane = channel 8 (r >> 2) + 4 h + (r & 3) of the tile).
     template <int NP>
-    __device__ __forceinline__ void apply(Act (&out)[NP][NT], const float (&x)[NP][KP], int h) const
+    __device__ __forceinline__ void apply(Act (&out)[NP][NT], const float (&x)[NP][KP], int h,
+                                          const floatx16 (*init)[NT] = nullptr) const
     {
         const floatx16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         floatx16 acc[NP][NT];
@@ -707,7 +710,7 @@ struct FirstLayer {
             for (int f = 0; f < NMF; ++f) xb[f] = fragment(hi, lo, (__bf16)1.f, (__bf16)1.f, f, h, false);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[g][t] = mfma(wa[t][0], xb[0], z);
+                acc[g][t] = mfma(wa[t][0], xb[0], init ? init[g][t] : z);
                 if constexpr (NMF == 2) acc[g][t] = mfma(wa[t][1], xb[1], acc[g][t]);
             }
         }
@@ -985,6 +988,7 @@ struct SaParams {
     int n, m, ns, cf;
     const float *xyz, *new_xyz, *feat;
     const bf16x8 *featp;                // NJF > 0: the features packed by fpn_sa_pack_features_bf16, or NULL (then feat)
+    const float *pre;                   // NJF = 0: (b,n,32 NT1) what wide features contribute to the first layer, or NULL
     const int *idx;
     const float *w1, *sc1, *sh1;        // NJF = 0 only: (3+cf, 32 NT1) fp32, scale, shift
     const bf16x8 *ws;
@@ -1095,7 +1099,23 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
             }
         }
         FPN_STAMP(1);
-        first.apply(a1, x, h);
+        if (p.pre) {            // (kernel-uniform)
+            floatx16 init[NP][NT1];
+#pragma unroll
+            for (int g = 0; g < NP; ++g)
+#pragma unroll
+                for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(p.pre + (b * p.n + pid[g]) * (long)(32 * NT1) + 32 * t +
+                                                                           8 * q + 4 * h);
+                        init[g][t][4 * q + 0] = v.x; init[g][t][4 * q + 1] = v.y;
+                        init[g][t][4 * q + 2] = v.z; init[g][t][4 * q + 3] = v.w;
+                    }
+            first.apply(a1, x, h, init);
+        } else {
+            first.apply(a1, x, h);
+        }
         FPN_STAMP(2);
         constexpr int U2 = ((NT2 + 1) / 2) * NT1;
         TileConst c2[2];        // (the arithmetic of the persistent kernel, bit for bit)
@@ -1134,12 +1154,12 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 #ifndef FPN_SAP_OCC
 #define FPN_SAP_OCC(np) ((np) == 1 ? 2 : 1)
 #endif
-template <int NT1, int NT2, int NT3, int NP, int KP>
-__global__ __launch_bounds__(64 * kWaves, FPN_SAP_OCC(NP)) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
-                                                                       unsigned balls_per_wave)
+template <int NT1, int NT2, int NT3, int NP, int KP, bool PRE = false>
+__global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
+                                                                                      unsigned balls_per_wave)
 {
     constexpr int U2 = ((NT2 + 1) / 2) * NT1, U3 = (NT3 / 2) * NT2, U = U2 + U3, C = 32 * NT3;
-    static_assert(U % kLdsAhead == 0 && NT3 == 4, "unsupported stack");
+    static_assert(U % kLdsAhead == 0, "unsupported stack");
     extern __shared__ bf16x8 sa_first_lds[];
     bf16x8 *wl = sa_first_lds;                                          // U + kLdsAhead units
     float *lsh2 = reinterpret_cast<float *>(wl + (U + kLdsAhead) * kUnitVecs);
@@ -1166,6 +1186,7 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SAP_OCC(NP)) void sa_first_bf16_ke
 
     int pid[NP];
     float xr[NP][KP], cr[3];
+    float4 pr[PRE ? NP : 1][NT1][4];        // PRE: the next round's rows of first-layer products, as they lie in memory
     auto load_idx = [&](unsigned c) {
 #pragma unroll
         for (int g = 0; g < NP; ++g) pid[g] = p.idx[(size_t)c * (32 * NP) + 32 * g + pt];
@@ -1183,6 +1204,13 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SAP_OCC(NP)) void sa_first_bf16_ke
                 if (k < 3) v = p.xyz[q * 3 + k];
                 else if (k < 3 + p.cf) v = p.feat[q * p.cf + k - 3];
                 xr[g][k] = v;
+            }
+            if constexpr (PRE) {
+#pragma unroll
+                for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        pr[g][t][i] = *reinterpret_cast<const float4 *>(p.pre + q * (32 * NT1) + 32 * t + 8 * i + 4 * h);
             }
         }
     };
@@ -1207,6 +1235,18 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SAP_OCC(NP)) void sa_first_bf16_ke
         for (int g = 0; g < NP; ++g)
 #pragma unroll
             for (int k = 0; k < KP; ++k) x[g][k] = k < 3 ? xr[g][k] - cr[k] : xr[g][k];
+        floatx16 init[PRE ? NP : 1][NT1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int g = 0; g < NP; ++g)
+#pragma unroll
+                for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        init[g][t][4 * i + 0] = pr[g][t][i].x; init[g][t][4 * i + 1] = pr[g][t][i].y;
+                        init[g][t][4 * i + 2] = pr[g][t][i].z; init[g][t][4 * i + 3] = pr[g][t][i].w;
+                    }
+        }
 #ifndef FPN_SAP_NOGATHER      // (timing-only builds, wrong results: FPN_SAP_NO*)
         load_x(min(c + 1, c1 - 1));
         load_idx(min(c + 2, c1 - 1));
@@ -1219,7 +1259,8 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SAP_OCC(NP)) void sa_first_bf16_ke
 
         Act a1[NP][NT1], a2[NP][NT2];
 #ifndef FPN_SAP_NOFIRST
-        first.apply(a1, x, h);
+        if constexpr (PRE) first.apply(a1, x, h, init);
+        else first.apply(a1, x, h);
 #else
 #pragma unroll
         for (int g = 0; g < NP; ++g)
@@ -1620,7 +1661,7 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
 {
     constexpr int U = ((NT2 + 1) / 2) * NT1 + (NT3 / 2) * NT2;
     constexpr size_t lds = (size_t)(U + kLdsAhead) * kUnitVecs * 16 + (32 * NT2 + 32 * NT3) * 4 + kWaves * 32 * NT3 * 4;
-    static_assert(lds <= 64 * 1024, "the stream does not fit the default LDS limit");
+    static_assert(lds <= 160 * 1024, "the stream does not fit LDS");
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         cus < 1)
@@ -1633,7 +1674,19 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
     if (groups >= 8) groups -= groups % 8;          // whole rounds over the XCDs (logical_block)
     const unsigned per_wave = (balls + groups * kWaves - 1) / (groups * kWaves);
     const dim3 grid(groups), block(64 * kWaves);
-    if (np == 2 && p.cf <= 1)
+    if (p.pre) {        // (with first-layer products there are no direct feature channels: KP = 4)
+        const void *fn = np == 2 ? reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4, true>)
+                                 : reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true>);
+        if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FPN_E_LAUNCH, "sa_chain_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
+        if (np == 2)
+            hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4, true>), grid, block, lds, st, p, balls, per_wave);
+        else
+            hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true>), grid, block, lds, st, p, balls, per_wave);
+        return check_launch("fpn_sa_chain_bf16");
+    }
+    if constexpr (lds > 64 * 1024) return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: this stack exists with first-layer products only");
+    else if (np == 2 && p.cf <= 1)
         hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4>), grid, block, lds, st, p, balls, per_wave);
     else if (np == 2)
         hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 8>), grid, block, lds, st, p, balls, per_wave);
@@ -1844,7 +1897,7 @@ int fpn_sa_chain_bf16_supported(int cf, int c1, int c2, int c3)
 }
 
 static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                         const float *new_xyz, const float *feat, const void *feat_packed, const int *idx,
+                         const float *new_xyz, const float *feat, const void *feat_packed, const float *pre, const int *idx,
                          const void *wstream, const float *const *consts, float *out, int ldo, int c3_valid,
                          void *stream)
 {
@@ -1854,6 +1907,8 @@ static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, in
                 "sa_chain_bf16: bad output width %d (c3 %d, ld %d)", c3_valid, c3, ldo);
     if (!fpn_sa_chain_bf16_supported(cf, c1, c2, c3))
         return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: no kernel for %d feature channels and layer widths %d,%d,%d", cf, c1, c2, c3);
+    if (cf < 32 && c1 == 128 && !pre)
+        return fail(FPN_E_UNSUPPORTED, "sa_chain_bf16: the 128-wide stack over coordinates exists with first-layer products only");
     if (b == 0) return FPN_OK;
     FPN_REQUIRE(xyz && new_xyz && idx && wstream && consts && out && (cf == 0 || feat || feat_packed), "sa_chain_bf16: null pointer");
     FPN_REQUIRE(!feat_packed || (cf >= 32 && (reinterpret_cast<uintptr_t>(feat_packed) & 15) == 0),
@@ -1863,6 +1918,7 @@ static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, in
     p.rows = (long)b * m * ns; p.n = n; p.m = m; p.ns = ns; p.cf = cf;
     p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.idx = idx;
     p.featp = static_cast<const bf16x8 *>(feat_packed);
+    p.pre = pre;
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     if (njf == 0) {       // consts: w1, scale1, shift1, shift2, shift3
         for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "sa_chain_bf16: constant %d is null", i);
@@ -1874,10 +1930,12 @@ static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, in
     p.out = out; p.ldo = ldo; p.c3 = c3_valid;
     hipStream_t st = as_stream(stream);
     if (njf == 0 && sa_persistent() && p.rows < (1L << 31)) {
+        if (t1 == 4) return launch_sa_first<4, 4, 8>(p, st);
         if (t2 == 2) return launch_sa_first<2, 2, 4>(p, st);
         if (t2 == 3) return launch_sa_first<2, 3, 4>(p, st);
         return launch_sa_first<2, 4, 4>(p, st);
     }
+    if (njf == 0 && t1 == 4) return launch_sa<0, 4, 4, 8>(p, st);
     if (njf == 0 && t2 == 2) return launch_sa<0, 2, 2, 4>(p, st);
     if (njf == 0 && t2 == 3) return launch_sa<0, 2, 3, 4>(p, st);
     if (njf == 0) return launch_sa<0, 2, 4, 4>(p, st);
@@ -1892,7 +1950,17 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
                       const float *new_xyz, const float *feat, const int *idx, const void *wstream,
                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
 {
-    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, idx, wstream, consts, out, ldo, c3_valid,
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, nullptr, idx, wstream, consts, out, ldo,
+                         c3_valid, stream);
+}
+
+int fpn_sa_chain_pre_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                          const float *new_xyz, const float *feat, const float *pre, const int *idx, const void *wstream,
+                          const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
+{
+    FPN_REQUIRE(cf <= 1, "sa_chain_pre_bf16: at most one direct feature channel beside the first-layer products (cf = %d)", cf);
+    FPN_REQUIRE((pre || b == 0) && (reinterpret_cast<uintptr_t>(pre) & 15) == 0, "sa_chain_pre_bf16: null or misaligned products");
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, pre, idx, wstream, consts, out, ldo, c3_valid,
                          stream);
 }
 
@@ -1901,8 +1969,8 @@ int fpn_sa_chain_bf16p(int b, int n, int m, int ns, int cf, int c1, int c2, int 
                        const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
 {
     FPN_REQUIRE(cf >= 32, "sa_chain_bf16p: packed features exist for cf >= 32 only (cf = %d)", cf);
-    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, nullptr, feat_packed, idx, wstream, consts, out, ldo,
-                         c3_valid, stream);
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, nullptr, feat_packed, nullptr, idx, wstream, consts, out,
+                         ldo, c3_valid, stream);
 }
 
 }  // extern "C"

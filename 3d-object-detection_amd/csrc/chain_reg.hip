@@ -596,15 +596,26 @@ __device__ __forceinline__ void layer_max(const floatx16 (&in)[NJ], const float4
 // First layer of a stack (K = 3..8 input channels straight from memory): out[NT] =
 // relu(bn(W1^T . x^T)), transposed.  x0..x3: the lane's inputs for MFMA steps 0..3, i.e.
 // channels 2s + h of its point (zero beyond the channel count); w1 (K, 32 NT) row-major.
+// pre: NULL, or the lane's row of products that other inputs of the layer have already
+// contributed (32 NT floats, before scale and shift): the accumulators start from them.
 template <int NT, int NSTEP>
 __device__ __forceinline__ void layer_first(floatx16 (&out)[NT], const float (&x)[NSTEP], const float *__restrict__ w1,
                                             int k_total, const float *__restrict__ sc, const float *__restrict__ sh,
-                                            unsigned lane, int h)
+                                            unsigned lane, int h, const float *__restrict__ pre = nullptr)
 {
     const int c = lane & 31;
+    if (pre) {          // (kernel-uniform) register r of tile t is channel 32 t + 8 (r >> 2) + 4 h + (r & 3)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(pre + 32 * t + 8 * q + 4 * h);
+                out[t][4 * q + 0] = v.x; out[t][4 * q + 1] = v.y; out[t][4 * q + 2] = v.z; out[t][4 * q + 3] = v.w;
+            }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        zero(out[t]);
+        if (!pre) zero(out[t]);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int k = 2 * s + h;
@@ -778,6 +789,11 @@ __global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const Obj
 //            the 3 relative coordinates ride in one more tile (its other 29 channels are
 //            zero, as are the matching rows of the caller's padded first-layer weights);
 //   NJF = 0: at most 8 input channels [dx,dy,dz, features...]: first layer from memory.
+//            With `pre`, wide point features have gone through their rows of the first
+//            layer ONCE PER POINT (the layer is linear before its scale, shift and ReLU, and
+//            a point is gathered into many balls: 8,192 gathered rows from 128 points per
+//            frustum in the second multi-scale level); the kernel gathers that row of
+//            products as the accumulators' starting values and adds the coordinates' part.
 // Layer widths are 32 NT1, 32 NT2, 32 NT3 (the caller pads narrower layers with zero
 // weights / scale / shift); columns >= c3 of the last layer are not written.
 // ---------------------------------------------------------------------------
@@ -787,6 +803,7 @@ struct SaChainParams {
     const float *xyz;     // (b,n,3)
     const float *new_xyz; // (b,m,3)
     const float *feat;    // (b,n,cf) or NULL
+    const float *pre;     // NJF = 0: (b,n,32 NT1) what wide point features contribute to the first layer, or NULL
     const int *idx;       // (b,m,ns)
     const float *w1; const float *sc1, *sh1;     // NJF > 0: chunked ((NJF+1)*32, 32 NT1); NJF = 0: plain (3+cf, 32 NT1)
     const float4 *w2; const float *sc2, *sh2;
@@ -863,7 +880,8 @@ __global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainP
             x[s] = v;
         }
         FPN_STAMP(1);
-        layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
+        layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h,
+                            p.pre ? p.pre + (b * p.n + pid) * (long)(32 * NT1) : nullptr);
         FPN_STAMP(2);
         layer_t<NT1, NT2, 0>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
         FPN_STAMP(3);
@@ -1114,15 +1132,18 @@ int fpn_sa_chain_supported(int cf, int c1, int c2, int c3)
     if (c1 % 64 || c2 % 32 || c3 % 128) return 0;
     if (c2 % 64) return njf == 0 && t1 == 2 && t2 == 3 && t3 == 4;      // a 96-wide middle layer, unpadded
     return (njf == 0 && t1 == 2 && t2 == 2 && t3 == 4) || (njf == 0 && t1 == 2 && t2 == 4 && t3 == 4) ||
+           (njf == 0 && t1 == 4 && t2 == 4 && t3 == 8) ||
            (njf == 10 && t1 == 2 && t2 == 2 && t3 == 4) || (njf == 10 && t1 == 4 && t2 == 4 && t3 == 8) ||
            (njf == 4 && t1 == 4 && t2 == 4 && t3 == 8);
 }
 
-int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                     const float *new_xyz, const float *feat, const int *idx, const float *const *layers,
-                     float *out, int ldo, int c3_valid, void *stream)
+static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                        const float *new_xyz, const float *feat, const float *pre, const int *idx,
+                        const float *const *layers, float *out, int ldo, int c3_valid, void *stream)
 {
     FPN_REQUIRE(b >= 0 && n >= 1 && m >= 1 && ns >= 1 && cf >= 0, "sa_chain: bad size");
+    FPN_REQUIRE(!pre || (cf < 32 && (reinterpret_cast<uintptr_t>(pre) & 15) == 0),
+                "sa_chain: first-layer products go with fewer than 32 direct feature channels and a 16-byte aligned array");
     FPN_REQUIRE(ns % 32 == 0, "sa_chain: samples per ball (%d) must be a multiple of 32", ns);
     // the last layer works on pairs of 32-channel tiles: a valid width ends on a pair
     FPN_REQUIRE(c3_valid >= 64 && c3_valid % 64 == 0 && c3_valid <= c3 && ldo >= c3_valid,
@@ -1134,19 +1155,35 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
     for (int i = 0; i < 9; ++i) FPN_REQUIRE(layers[i], "sa_chain: layer parameter %d is null", i);
     SaChainParams p{};
     p.rows = (long)b * m * ns; p.n = n; p.m = m; p.ns = ns; p.cf = cf;
-    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.idx = idx;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.pre = pre; p.idx = idx;
     p.w1 = layers[0]; p.sc1 = layers[1]; p.sh1 = layers[2];
     p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
     p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
     p.out = out; p.ldo = ldo; p.c3 = c3_valid;
     const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32;
     hipStream_t st = as_stream(stream);
+    if (njf == 0 && t1 == 4) return launch_sa_chain<0, 4, 4, 8>(p, st);
     if (njf == 0 && t2 == 2) return launch_sa_chain<0, 2, 2, 4>(p, st);
     if (njf == 0 && t2 == 3) return launch_sa_chain<0, 2, 3, 4>(p, st);
     if (njf == 0) return launch_sa_chain<0, 2, 4, 4>(p, st);
     if (njf == 10 && t1 == 2) return launch_sa_chain<10, 2, 2, 4>(p, st);
     if (njf == 10) return launch_sa_chain<10, 4, 4, 8>(p, st);
     return launch_sa_chain<4, 4, 4, 8>(p, st);
+}
+
+int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                     const float *new_xyz, const float *feat, const int *idx, const float *const *layers,
+                     float *out, int ldo, int c3_valid, void *stream)
+{
+    return sa_chain_f32(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, idx, layers, out, ldo, c3_valid, stream);
+}
+
+int fpn_sa_chain_pre_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
+                         const float *new_xyz, const float *feat, const float *pre, const int *idx,
+                         const float *const *layers, float *out, int ldo, int c3_valid, void *stream)
+{
+    FPN_REQUIRE(pre || b == 0, "sa_chain_pre: null pointer");
+    return sa_chain_f32(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, pre, idx, layers, out, ldo, c3_valid, stream);
 }
 
 int fpn_fp_head_chain_f32(long rows, int ca, int cb, const float *xa, const float *xb,

@@ -135,17 +135,23 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     # padded widths: the middle layer to a multiple of 32 where a kernel exists for that
     # (96 stays 96), else of 64
     pad = None
+    supported = _lib.load().fpn_sa_chain_bf16_supported if SA_PRECISION == "bf16" else _lib.load().fpn_sa_chain_supported
+    # wide features go through their rows of the first layer once per point, outside the kernel
+    hoist = HOIST_FEATURES and cf >= 32
     for mid in (32, 64):
         cand = (_round_up(widths[0], 64), _round_up(widths[1], mid), _round_up(widths[2], 128))
-        supported = _lib.load().fpn_sa_chain_bf16_supported if SA_PRECISION == "bf16" else _lib.load().fpn_sa_chain_supported
+        if hoist and supported(0, *cand):
+            pad = cand
+            break
         if supported(cf, *cand):
             pad = cand
+            hoist = False
             break
     if pad is None:
         # the variables are created by the per-layer path
         return None
     cache = store.__dict__.setdefault("_sa_chain_cache", {})
-    key = (names[0], cf, xyz_first, SA_PRECISION)
+    key = (names[0], cf, xyz_first, SA_PRECISION, hoist)
     hit = cache.get(key)
     if hit is not None and hit["version"] == store.version:
         return hit
@@ -165,7 +171,9 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     w1, s1, h1 = params[0]
     xyz_rows = w1[:3] if xyz_first else w1[cf:cf + 3]
     feat_rows = w1[3:] if xyz_first else w1[:cf]
-    if cf >= 32:
+    if hoist:
+        w1k, s1p, h1p = padded(xyz_rows, s1, h1, 3, pad[0])
+    elif cf >= 32:
         w1k, s1p, h1p = padded(torch.cat([feat_rows, xyz_rows], 0), s1, h1, cf + 32, pad[0])
         w1k = ops.tile_weights_reg(w1k, 0)
     else:
@@ -175,7 +183,10 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     if SA_PRECISION == "bf16":
         # one bf16 weight stream (scales folded into the columns); fp32 first layer when
         # it reads the coordinates and features straight from memory (cf < 32)
-        if cf >= 32:
+        if hoist:
+            stream = ops.chain_stream_bf16([(w2p, s2p), (w3p, s3p)])
+            tensors = [w1k.contiguous(), s1p, h1p, h2p, h3p]
+        elif cf >= 32:
             # the kernel feeds every coordinate as two bf16 numbers (rows cf..cf+2 and cf+4..cf+6): the same weights twice
             w1p = padded(torch.cat([feat_rows, xyz_rows, torch.zeros_like(xyz_rows[:1]), xyz_rows], 0), s1, h1, cf + 32,
                          pad[0])[0]
@@ -192,13 +203,26 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
             tensors = [w1k.contiguous(), s1p, h1p, h2p, h3p]
         plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "pad": pad,
                 "stream": stream}
+        if hoist:       # the features' rows of the first layer, scaled like the stream's weights, columns padded
+            plan["w1f"] = padded(feat_rows, None, h1, cf, pad[0])[0].contiguous()
+            plan["s1"] = s1p
+            plan["w1f_bf16"] = ops.pack_mlp_bf16(plan["w1f"])
     else:
         tensors = [w1k.contiguous(), s1p, h1p, ops.tile_weights_reg(w2p, 0), s2p, h2p, ops.tile_weights_reg(w3p, 0),
                    s3p, h3p]
         plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "pad": pad}
+        if hoist:       # the features' rows of the first layer, columns padded like the layer: no scale, no shift
+            plan["w1f"] = padded(feat_rows, None, h1, cf, pad[0])[0].contiguous()
     cache[key] = plan
     return plan
 
+
+# A set-abstraction layer is linear before its batch norm and ReLU, and a point is gathered
+# into many balls: wide point features are multiplied with their rows of the first layer ONCE
+# PER POINT and the fused kernel gathers that product (fpn_sa_chain_pre_f32) instead of the
+# features.  False: the kernel gathers the features and multiplies per gathered row (the
+# reference's order of operations; the same results up to fp32 rounding).
+HOIST_FEATURES = True
 
 # Under SA_PRECISION = "bf16": point features wider than 32 channels are converted to the
 # kernel's operand form once per module instead of once per gathered row (False: gathered as
@@ -238,18 +262,33 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
     ldo = out2d.stride(0) if out2d.shape[0] > 1 else max(out2d.stride(0), out2d.shape[1])
     obs = ops.launch_observer
     tok = None
-    if obs is not None:       # algorithmic work: the unpadded layer widths
-        macs = (3 + cf) * widths[0] + widths[0] * widths[1] + widths[1] * widths[2]
-        tok = obs.begin("sa_chain%s[cf=%d,%d-%d-%d]" % ("_bf16" if "stream" in plan else "", cf, *widths),
+    hoisted = "w1f" in plan
+    if obs is not None:       # algorithmic work: the unpadded layer widths (hoisted: the features' rows of the
+        # first layer are another launch's work, once per point)
+        macs = (3 + (0 if hoisted else cf)) * widths[0] + widths[0] * widths[1] + widths[1] * widths[2]
+        tok = obs.begin("sa_chain%s[cf=%d,%d-%d-%d%s]" % ("_bf16" if "stream" in plan else "", 0 if hoisted else cf, *widths,
+                                                           ",pre=%d" % cf if hoisted else ""),
                         b * m * ns, 0, 0, macs=b * m * ns * macs)
     with torch.cuda.device(xyz.device):
-        if "stream" in plan:
+        if "stream" in plan and hoisted:
+            pre = ops.shared_mlp(points.reshape(b * n, cf), plan["w1f"], plan["s1"], None, relu=False, wt_bf16=plan["w1f_bf16"])
+            _lib.check(_lib.load().fpn_sa_chain_pre_bf16(b, n, m, ns, 0, pad[0], pad[1], pad[2], _lib.ptr(xyz),
+                                                         _lib.ptr(new_xyz), None, _lib.ptr(pre), _lib.ptr(idx),
+                                                         _lib.ptr(plan["stream"]), plan["table"], _lib.ptr(out2d), ldo,
+                                                         int(widths[2]), _lib.stream_of(xyz)))
+        elif "stream" in plan:
             if packed is None and PACK_FEATURES and cf >= 32 and cf % 32 == 0:
                 packed = _pack_features(points)
             entry = _lib.load().fpn_sa_chain_bf16 if packed is None else _lib.load().fpn_sa_chain_bf16p
             _lib.check(entry(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz), _lib.ptr(new_xyz),
                              _lib.ptr(points if packed is None else packed), _lib.ptr(idx), _lib.ptr(plan["stream"]),
                              plan["table"], _lib.ptr(out2d), ldo, int(widths[2]), _lib.stream_of(xyz)))
+        elif "w1f" in plan:
+            # (:184 before :187-190 in the reference's order: per gathered row; here per point, then gathered)
+            pre = ops.shared_mlp(points.reshape(b * n, cf), plan["w1f"], None, None, relu=False)
+            _lib.check(_lib.load().fpn_sa_chain_pre_f32(b, n, m, ns, 0, pad[0], pad[1], pad[2], _lib.ptr(xyz),
+                                                        _lib.ptr(new_xyz), None, _lib.ptr(pre), _lib.ptr(idx), plan["table"],
+                                                        _lib.ptr(out2d), ldo, int(widths[2]), _lib.stream_of(xyz)))
         else:
             _lib.check(_lib.load().fpn_sa_chain_f32(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
                                                     _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx), plan["table"],

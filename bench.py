@@ -137,13 +137,14 @@ def pmc_kernel_prefix(obs_name):
              "v1_obj_chain_box": "obj_chain_reg_kernel<true>", "v1_obj_chain_tnet": "obj_chain_reg_kernel<false>",
              "v1_seg_tail_bf16": "seg_tail_bf16_kernel", "v1_seg_head_bf16": "seg_head_bf16_kernel",
              "v1_obj_chain_box_bf16": "obj_chain_bf16_kernel<true", "v1_obj_chain_tnet_bf16": "obj_chain_bf16_kernel<false",
-             "fp_head_chain": "fp_head_reg_kernel", "fp_head_chain_bf16": "fp_head_bf16_kernel"}
+             "fp_head_chain": "fp_head_reg_kernel", "fp_head_chain_bf16": ("fp_head_lds_bf16_kernel", "fp_head_bf16_kernel")}
     if obs_name in fixed:
         return fixed[obs_name]
     if obs_name.startswith("sa_chain"):
         # "sa_chain[_bf16][cf=C,w1-w2-w3]" -> template arguments <cf/32, padded widths / 32>
+        # (a third field ",pre=C": wide features went through the first layer once per point, in another launch)
         inside = obs_name[obs_name.index("[") + 1:-1]
-        cf_s, widths = inside.split(",")
+        cf_s, widths = inside.split(",")[:2]
         cf = int(cf_s[3:])
         w = [int(v) for v in widths.split("-")]
         up = lambda v, q: (v + q - 1) // q * q        # noqa: E731
@@ -152,6 +153,8 @@ def pmc_kernel_prefix(obs_name):
         # the middle layer runs at a multiple of 32 after a 64-wide first layer (96 stays 96)
         w2 = up(w[1], 32) if (cf < 32 and w1 == 64 and up(w[1], 32) == 96) else up(w[1], 64)
         targs = "%d, %d, %d, %d" % (cf // 32 if cf >= 32 else 0, w1 // 32, w2 // 32, up(w[2], 128) // 32)
+        if bf16 and cf < 32:      # the persistent kernel of the stacks over coordinates
+            return "sa_first_bf16_kernel<%s," % targs[3:]
         return ("sa_chain_bf16_kernel<%s," if bf16 else "sa_chain_kernel<%s>") % targs
     return None
 

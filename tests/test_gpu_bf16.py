@@ -162,7 +162,7 @@ def test_bf16_set_abstraction_within_stated_bound(device):
                 st.randomize_batch_norm(7)
                 continue
             outs[precision] = feat.cpu().numpy()
-        assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
+        assert any(len(k) >= 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
         err = scaled_err(outs["bf16"], outs["fp32"])
         assert 1e-6 < err <= BF16_RTOL, (kind, args[0], err)
         print(kind, args if kind == "all" else args[0], "bf16 vs fp32: %.4f" % err)
@@ -380,7 +380,8 @@ def test_bf16_packed_features_bit_for_bit(device):
         st = variables.VariableStore(device, seed=6)
         got = {}
         for flag in (True, False, True):
-            U.SA_PRECISION, U.PACK_FEATURES = "bf16", flag
+            # (the kernels that gather the features themselves: not the form that gathers first-layer products)
+            U.SA_PRECISION, U.PACK_FEATURES, U.HOIST_FEATURES = "bf16", flag, False
             try:
                 with variables.use_store(st):
                     if kind == "msg":
@@ -389,7 +390,7 @@ def test_bf16_packed_features_bit_for_bit(device):
                         _, feat, _ = U.pointnet_sa_module(dev(xyz, device), dev(pts, device), *args, None, False, False, None,
                                                           scope='s')
             finally:
-                U.SA_PRECISION, U.PACK_FEATURES = "fp32", True
+                U.SA_PRECISION, U.PACK_FEATURES, U.HOIST_FEATURES = "fp32", True, True
             got[flag] = feat.clone()
         assert torch.equal(got[True], got[False]), kind
         assert got[True].abs().max() > 0
@@ -400,7 +401,8 @@ def test_bf16_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
     (weights resident in LDS, a wave walks whole balls) and the kernel launched per point
     group (FPN_BF16_SA=launch) give the same bits - three stack shapes, one and two point
     groups per wave, one to four rounds per ball, 0 / 1 / 4 feature channels beside the
-    coordinates, ball counts that leave waves and whole workgroups without work."""
+    coordinates, ball counts that leave waves and whole workgroups without work; and with
+    wide features, whose first-layer products both kernels gather."""
     from fpn import pointnet_util as U
     from fpn import variables
     rng = np.random.RandomState(9)
@@ -408,7 +410,11 @@ def test_bf16_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
              ("ssg", 2, 512, 0, (5, 0.3, 32, [64, 96, 128])),
              ("ssg", 1, 512, 4, (3, 0.3, 128, [64, 128, 128])),
              ("ssg", 5, 700, 1, (129, 0.25, 256, [64, 64, 128])),
-             ("ssg", 40, 256, 0, (128, 0.3, 64, [64, 96, 128]))]
+             ("ssg", 40, 256, 0, (128, 0.3, 64, [64, 96, 128])),
+             # wide features: the kernels gather first-layer products made once per point
+             ("msg", 3, 128, 320, (32, [0.4, 0.8, 1.6], [64, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]])),
+             ("ssg", 2, 128, 128, (7, 0.5, 32, [128, 128, 256])),
+             ("ssg", 9, 96, 64, (33, 0.4, 64, [64, 64, 128]))]
     for kind, b, n, cf, args in cases:
         xyz = dev(rng.uniform(0, 1, (b, n, 3)).astype(np.float32), device)
         pts = dev(rng.standard_normal((b, n, cf)).astype(np.float32), device) if cf else None
@@ -429,7 +435,7 @@ def test_bf16_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
             finally:
                 U.SA_PRECISION = "fp32"
             got[mode] = feat.clone()
-        assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
+        assert any(len(k) >= 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernel not taken"
         assert torch.equal(got["persistent"], got["launch"]), (kind, b, args[0])
         assert got["persistent"].abs().max() > 0
 

@@ -125,7 +125,7 @@ def test_v2_bf16_2048_points_against_float64_oracle(device):
     pc[..., :3] *= 0.05      # bring the metric frustum into the radius range of the SA modules
     st = _v2_store(device, pc, one_hot)
     ep = _v2_forward(device, st, pc, one_hot, "bf16")
-    assert any(len(k) == 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernels not taken"
+    assert any(len(k) >= 4 and k[3] == "bf16" for k in st.__dict__["_sa_chain_cache"]), "bf16 kernels not taken"
     params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
     pc64, oh64 = pc.astype(np.float64), one_hot.astype(np.float64)
     worst = {}

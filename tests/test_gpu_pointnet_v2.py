@@ -190,6 +190,22 @@ def test_sa_chain_kernels(device):
         assert outs[True].shape == wf.shape
         close(outs[True], wf)
         close(outs[True], outs[False], 1e-4)
+        if pts is not None and pts.shape[2] >= 32:
+            # wide features: multiplied once per point and gathered as products (the default), or gathered and
+            # multiplied per row inside the kernel - the same layer up to fp32 rounding
+            assert any(k[-1] is True for k in st.__dict__["_sa_chain_cache"]), "hoisted form not taken"
+            U.HOIST_FEATURES = False
+            try:
+                with variables.use_store(st):
+                    if kind == "msg":
+                        _, feat = U.pointnet_sa_module_msg(dev(xyz, device), dev(pts, device), *args, False, None, scope='s')
+                    else:
+                        _, feat, _ = U.pointnet_sa_module(dev(xyz, device), dev(pts, device), *args, None, False, False, None,
+                                                          scope='s')
+            finally:
+                U.HOIST_FEATURES = True
+            assert any(k[-1] is False and k[1] >= 32 for k in st.__dict__["_sa_chain_cache"]), "in-kernel form not taken"
+            close(outs[True], feat.cpu().numpy(), 1e-5)
 
 
 @pytest.mark.parametrize("cb", [4, 0, 32])
