@@ -812,8 +812,9 @@ struct SaChainParams {
     int ldo, c3;
 };
 
+// (NJF = 0: all four shapes fit two waves per SIMD - the 128-128-256 one with ten registers squeezed out)
 template <int NJF, int NT1, int NT2, int NT3>
-__global__ __launch_bounds__(64 * kRegWaves) void sa_chain_kernel(const SaChainParams p)
+__global__ __launch_bounds__(64 * kRegWaves, NJF == 0 ? 2 : 1) void sa_chain_kernel(const SaChainParams p)
 {
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
@@ -917,7 +918,7 @@ struct FpHeadParams {
 };
 
 template <int NJA>
-__global__ __launch_bounds__(64 * kRegWaves) void fp_head_reg_kernel(const FpHeadParams p)
+__global__ __launch_bounds__(64 * kRegWaves, 2) void fp_head_reg_kernel(const FpHeadParams p)
 {
     constexpr int NJ = NJA + 1;
     const unsigned lane = threadIdx.x & 63;
