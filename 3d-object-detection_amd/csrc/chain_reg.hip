@@ -633,6 +633,56 @@ __device__ __forceinline__ void layer_first(floatx16 (&out)[NT], const float (&x
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The same layer with its weights and constants loaded ahead: they are the same for every
+// point of the wave and depend on nothing the kernel computes, so a kernel whose inputs come
+// through a chain of dependent loads (ball index -> coordinates) issues load() BEFORE that
+// chain and the latencies overlap (inside layer_first the loads sit between the MFMAs).
+template <int NT, int NSTEP>
+struct FirstLayerF32 {
+    float wv[NT][NSTEP];
+    TileConst csc[NT], csh[NT];
+
+    __device__ __forceinline__ void load(const float *__restrict__ w1, int k_total, const float *__restrict__ sc,
+                                         const float *__restrict__ sh, unsigned lane, int h)
+    {
+        const int c = lane & 31;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int k = 2 * s + h;
+                wv[t][s] = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
+            }
+            load_const(csc[t], sc, 32 * t + 4 * h);
+            load_const(csh[t], sh, 32 * t + 4 * h);
+        }
+    }
+
+    // pre: as for layer_first
+    __device__ __forceinline__ void apply(floatx16 (&out)[NT], const float (&x)[NSTEP], int h,
+                                          const float *__restrict__ pre = nullptr) const
+    {
+        if (pre) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(pre + 32 * t + 8 * q + 4 * h);
+                    out[t][4 * q + 0] = v.x; out[t][4 * q + 1] = v.y; out[t][4 * q + 2] = v.z; out[t][4 * q + 3] = v.w;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (!pre) zero(out[t]);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], x[s], out[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bn_relu(out[t], csc[t], csh[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // seg head: conv1 .. conv5 + max over points
 // ---------------------------------------------------------------------------
@@ -868,6 +918,8 @@ __global__ __launch_bounds__(64 * kRegWaves, NJF == 0 ? 2 : 1) void sa_chain_ker
         if (pool.on) layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, lmax + pool.local * C, ring, lane, h, p.c3);
         else layer_max<NT2, NT3, P2>(a2, p.w3, p.sc3, p.sh3, gmax, ring, lane, h, p.c3);
     } else {
+        FirstLayerF32<NT1, 4> first;
+        first.load(p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
         load_chunk(ring[0], p.w2, lane);
         load_chunk(ring[1], p.w2 + (size_t)NT1 * 256, lane);
         // input channel k = 2s + h of this lane: dx, dy, dz, then the point's features
@@ -881,8 +933,7 @@ __global__ __launch_bounds__(64 * kRegWaves, NJF == 0 ? 2 : 1) void sa_chain_ker
             x[s] = v;
         }
         FPN_STAMP(1);
-        layer_first<NT1, 4>(a1, x, p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h,
-                            p.pre ? p.pre + (b * p.n + pid) * (long)(32 * NT1) : nullptr);
+        first.apply(a1, x, h, p.pre ? p.pre + (b * p.n + pid) * (long)(32 * NT1) : nullptr);
         FPN_STAMP(2);
         layer_t<NT1, NT2, 0>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
         FPN_STAMP(3);
