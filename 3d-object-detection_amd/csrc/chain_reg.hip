@@ -951,6 +951,80 @@ __global__ __launch_bounds__(64 * kRegWaves, NJF == 0 ? 2 : 1) void sa_chain_ker
 }
 
 // ---------------------------------------------------------------------------
+// The narrow stack of the first multi-scale level, (3 + cf) -> 32 -> 32 -> 64 + max, at its
+// own widths.  Padded to the 64-64-128 kernel it ran 200 MFMAs per 32 rows, three quarters
+// of them on zeros; here it is 4 + 16 + 32.  All its weights fit a lane's registers (one
+// chunk for the 32 x 32 layer, two for the 32 x 64 one), so the kernel is persistent: a wave
+// loads them once and walks consecutive groups of 32 samples, the next group's coordinates
+// and the one after's ball indices in flight while it multiplies.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kRegWaves, 2) void sa_small_kernel(const SaChainParams p, unsigned groups,
+                                                                     unsigned groups_per_wave)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5, c = lane & 31;
+    const unsigned gw = __builtin_amdgcn_readfirstlane(logical_block(1) * kRegWaves + (threadIdx.x >> 6));
+    const unsigned g0 = gw * groups_per_wave, g1 = min(groups, g0 + groups_per_wave);
+    if (g0 >= g1) return;
+    const unsigned gpb = p.ns / 32;         // groups per ball
+
+    int pid = p.idx[(size_t)g0 * 32 + pt];
+    FirstLayerF32<1, 4> first;
+    first.load(p.w1, 3 + p.cf, p.sc1, p.sh1, lane, h);
+    WChunk w2, w3a, w3b;
+    load_chunk(w2, p.w2, lane);
+    load_chunk(w3a, p.w3, lane);
+    load_chunk(w3b, p.w3 + 256, lane);
+    TileConst csc2, csh2;
+    load_const(csc2, p.sc2, 4 * h);
+    load_const(csh2, p.sh2, 4 * h);
+    const float sc3a = p.sc3[c], sh3a = p.sh3[c], sc3b = p.sc3[32 + c], sh3b = p.sh3[32 + c];
+
+    // input channel k = 2 s + h of this lane: dx, dy, dz, then the point's direct features
+    float xr[4], cr[4];
+    auto load_x = [&](unsigned g) {         // raw values: nothing here waits for a load it has issued itself
+        const unsigned ball = g / gpb, b = ball / p.m;
+        const size_t q = (size_t)b * p.n + pid;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 2 * s + h;
+            float v = 0.f, ctr = 0.f;
+            if (k < 3) {
+                v = p.xyz[q * 3 + k];
+                ctr = p.new_xyz[(size_t)ball * 3 + k];
+            } else if (k < 3 + p.cf) {
+                v = p.feat[q * p.cf + k - 3];
+            }
+            xr[s] = v;
+            cr[s] = ctr;
+        }
+    };
+    load_x(g0);
+    pid = p.idx[(size_t)min(g0 + 1, g1 - 1) * 32 + pt];
+#pragma unroll 1
+    for (unsigned g = g0; g < g1; ++g) {
+        float x[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x[s] = xr[s] - cr[s];
+        load_x(min(g + 1, g1 - 1));
+        pid = p.idx[(size_t)min(g + 2, g1 - 1) * 32 + pt];
+        __builtin_amdgcn_sched_barrier(0);
+
+        floatx16 a1[1], a2, acc0, acc1;
+        first.apply(a1, x, h);
+        zero(a2);
+        mfma_single(a2, w2, a1[0]);
+        bn_relu(a2, csc2, csh2);
+        zero(acc0);
+        zero(acc1);
+        mfma_pair_n(acc0, acc1, w3a, w3b, a2);
+        int *gmax = reinterpret_cast<int *>(p.out + (size_t)(g / gpb) * p.ldo);
+        max_points(acc0, sc3a, sh3a, gmax + c, h);
+        max_points(acc1, sc3b, sh3b, gmax + 32 + c, h);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Per-point head after a feature-propagation step: the concatenation
 // [interpolated features (32 NJA channels) | the point's own features (cb <= 32)]
 // (models/pointnet_util.py:218) through three 128-wide layers and a final 128 -> 2
@@ -1179,6 +1253,7 @@ int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *
 
 int fpn_sa_chain_supported(int cf, int c1, int c2, int c3)
 {
+    if (cf <= 5 && c1 == 32 && c2 == 32 && c3 == 64) return 1;      // the narrow stack at its own widths
     const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32, t3 = c3 / 32;
     if (cf >= 32 ? cf % 32 != 0 : cf > 5) return 0;
     if (c1 % 64 || c2 % 32 || c3 % 128) return 0;
@@ -1214,6 +1289,20 @@ static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int
     p.out = out; p.ldo = ldo; p.c3 = c3_valid;
     const int njf = cf >= 32 ? cf / 32 : 0, t1 = c1 / 32, t2 = c2 / 32;
     hipStream_t st = as_stream(stream);
+    if (c1 == 32) {
+        FPN_REQUIRE(!pre, "sa_chain: the 32-32-64 stack takes no first-layer products");
+        FPN_REQUIRE(p.rows / 32 < (1L << 31), "sa_chain: too many rows");
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1)
+            return fail(FPN_E_LAUNCH, "sa_chain: cannot read the device's CU count");
+        const unsigned groups = (unsigned)(p.rows / 32);
+        unsigned wgs = std::min<unsigned>((unsigned)cus * 2, (groups + kRegWaves - 1) / kRegWaves);
+        if (wgs >= 8) wgs -= wgs % 8;           // whole rounds over the XCDs (logical_block)
+        const unsigned per_wave = (groups + wgs * kRegWaves - 1) / (wgs * kRegWaves);
+        hipLaunchKernelGGL(sa_small_kernel, dim3(wgs), dim3(64 * kRegWaves), 0, st, p, groups, per_wave);
+        return check_launch("fpn_sa_chain_f32");
+    }
     if (njf == 0 && t1 == 4) return launch_sa_chain<0, 4, 4, 8>(p, st);
     if (njf == 0 && t2 == 2) return launch_sa_chain<0, 2, 2, 4>(p, st);
     if (njf == 0 && t2 == 3) return launch_sa_chain<0, 2, 3, 4>(p, st);

@@ -138,8 +138,12 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
     supported = _lib.load().fpn_sa_chain_bf16_supported if SA_PRECISION == "bf16" else _lib.load().fpn_sa_chain_supported
     # wide features go through their rows of the first layer once per point, outside the kernel
     hoist = HOIST_FEATURES and cf >= 32
-    for mid in (32, 64):
-        cand = (_round_up(widths[0], 64), _round_up(widths[1], mid), _round_up(widths[2], 128))
+    narrow = (_round_up(widths[0], 32), _round_up(widths[1], 32), _round_up(widths[2], 64))
+    for mid in (0, 32, 64):
+        # (first the widths rounded to whole 32-channel tiles only: a kernel exists for 32-32-64 in fp32)
+        cand = narrow if mid == 0 else (_round_up(widths[0], 64), _round_up(widths[1], mid), _round_up(widths[2], 128))
+        if mid == 0 and (cf >= 32 or not supported(cf, *cand)):
+            continue
         if hoist and supported(0, *cand):
             pad = cand
             break

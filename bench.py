@@ -153,6 +153,8 @@ def pmc_kernel_prefix(obs_name):
         # the middle layer runs at a multiple of 32 after a 64-wide first layer (96 stays 96)
         w2 = up(w[1], 32) if (cf < 32 and w1 == 64 and up(w[1], 32) == 96) else up(w[1], 64)
         targs = "%d, %d, %d, %d" % (cf // 32 if cf >= 32 else 0, w1 // 32, w2 // 32, up(w[2], 128) // 32)
+        if not bf16 and cf < 32 and w == [32, 32, 64]:
+            return "sa_small_kernel"
         if bf16 and cf < 32:      # the persistent kernel of the stacks over coordinates
             return "sa_first_bf16_kernel<%s," % targs[3:]
         return ("sa_chain_bf16_kernel<%s," if bf16 else "sa_chain_kernel<%s>") % targs
