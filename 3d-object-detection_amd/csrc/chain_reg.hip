@@ -30,6 +30,8 @@
 // (90 % of the fp32 MFMA peak) against 3.49 ms for the LDS-resident version of the same
 // chain that this replaced (8 waves sharing a 64-point tile, 7 barriers per tile).
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include <cstdint>
 #include <type_traits>
 #include <utility>
@@ -951,6 +953,152 @@ __global__ __launch_bounds__(64 * kRegWaves, NJF == 0 ? 2 : 1) void sa_chain_ker
 }
 
 // ---------------------------------------------------------------------------
+// sa_chain_kernel's NJF = 0 form as a PERSISTENT kernel, for the stacks whose second and
+// third layer fit LDS (64-64-128: 48 KiB, 64-96-128: 72 KiB).  A wave launched per 32 samples
+// spends a quarter to a third of its life outside MFMAs - ball index -> coordinates -> first
+// layer, the first weight chunks from memory, the workgroup's barriers around the pooled
+// maxima.  Here a workgroup copies both layers' chunks and constants into LDS once; a wave
+// walks whole balls, 32 samples a round, its weight ring refilled from LDS; the only memory
+// reads inside a round are the next round's coordinates (and first-layer products) and the
+// round after's ball indices, not waited for until the next round begins; a ball's maxima meet
+// in the wave's own LDS row and the wave stores the finished row itself (no memory atomics,
+// no barrier after the set-up).  Same arithmetic as sa_chain_kernel, operation by operation.
+// ---------------------------------------------------------------------------
+template <int NT1, int NT2, int NT3, bool PRE>
+__global__ __launch_bounds__(64 * kRegWaves, 2) void sa_persist_kernel(const SaChainParams p, unsigned balls,
+                                                                       unsigned balls_per_wave)
+{
+    constexpr int C = 32 * NT3, W2 = NT1 * NT2 * 256, W3 = NT2 * NT3 * 256;     // float4 per layer
+    extern __shared__ float4 sa_persist_lds[];
+    float4 *lw2 = sa_persist_lds, *lw3 = lw2 + W2;
+    float *lsc2 = reinterpret_cast<float *>(lw3 + W3), *lsh2 = lsc2 + 32 * NT2, *lsc3 = lsh2 + 32 * NT2, *lsh3 = lsc3 + C;
+    float *lsc1 = lsh3 + C, *lsh1 = lsc1 + 32 * NT1;
+    int *lmax = reinterpret_cast<int *>(lsh1 + 32 * NT1) + (threadIdx.x >> 6) * C;
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    for (int i = threadIdx.x; i < W2; i += 64 * kRegWaves) lw2[i] = p.w2[i];
+    for (int i = threadIdx.x; i < W3; i += 64 * kRegWaves) lw3[i] = p.w3[i];
+    for (int i = threadIdx.x; i < 32 * NT2; i += 64 * kRegWaves) {
+        lsc2[i] = p.sc2[i];
+        lsh2[i] = p.sh2[i];
+    }
+    for (int i = threadIdx.x; i < C; i += 64 * kRegWaves) {
+        lsc3[i] = p.sc3[i];
+        lsh3[i] = p.sh3[i];
+    }
+    for (int i = threadIdx.x; i < 32 * NT1; i += 64 * kRegWaves) {
+        lsc1[i] = p.sc1[i];
+        lsh1[i] = p.sh1[i];
+    }
+    for (int i = lane; i < C; i += 64) lmax[i] = 0;
+    __syncthreads();
+
+    const unsigned gw = __builtin_amdgcn_readfirstlane(logical_block(1) * kRegWaves + (threadIdx.x >> 6));
+    const unsigned ball0 = gw * balls_per_wave, ball1 = min(balls, ball0 + balls_per_wave);
+    if (ball0 >= ball1) return;
+    const unsigned rpb = p.ns / 32;             // rounds per ball
+    const unsigned c0 = ball0 * rpb, c1 = ball1 * rpb;
+
+    int pid = p.idx[(size_t)c0 * 32 + pt];
+    // the first layer's weights stay in registers (one per tile and MFMA step); its scales and shifts are read
+    // from LDS every round
+    float wv[NT1][4];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 2 * s + h;
+            wv[t][s] = k < 3 + p.cf ? p.w1[k * (32 * NT1) + 32 * t + (lane & 31)] : 0.f;
+        }
+    // input channel k = 2 s + h of this lane: dx, dy, dz, then the point's direct features
+    float xr[4], cr[4];
+    float4 pr[PRE ? NT1 : 1][4];                // PRE: the next round's row of first-layer products
+    auto load_x = [&](unsigned c) {             // raw values: nothing here waits for a load it has issued itself
+        const unsigned ball = c / rpb, b = ball / p.m;
+        const size_t q = (size_t)b * p.n + pid;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 2 * s + h;
+            float v = 0.f, ctr = 0.f;
+            if (k < 3) {
+                v = p.xyz[q * 3 + k];
+                ctr = p.new_xyz[(size_t)ball * 3 + k];
+            } else if (k < 3 + p.cf) {
+                v = p.feat[q * p.cf + k - 3];
+            }
+            xr[s] = v;
+            cr[s] = ctr;
+        }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    pr[t][i] = *reinterpret_cast<const float4 *>(p.pre + q * (32 * NT1) + 32 * t + 8 * i + 4 * h);
+        }
+    };
+    load_x(c0);
+    pid = p.idx[(size_t)min(c0 + 1, c1 - 1) * 32 + pt];
+
+    WChunk ring[4];
+    unsigned ball = ball0, in_ball = 0;
+#pragma unroll 1
+    for (unsigned c = c0; c < c1; ++c) {
+        float x[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x[s] = xr[s] - cr[s];
+        floatx16 a1[NT1], a2[NT2];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            if constexpr (PRE) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a1[t][4 * i + 0] = pr[t][i].x; a1[t][4 * i + 1] = pr[t][i].y;
+                    a1[t][4 * i + 2] = pr[t][i].z; a1[t][4 * i + 3] = pr[t][i].w;
+                }
+            } else {
+                zero(a1[t]);
+            }
+        }
+        load_x(min(c + 1, c1 - 1));
+        pid = p.idx[(size_t)min(c + 2, c1 - 1) * 32 + pt];
+        load_chunk(ring[0], lw2, lane);
+        load_chunk(ring[1], lw2 + (size_t)NT1 * 256, lane);
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], x[s], a1[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            TileConst csc, csh;
+            load_const(csc, lsc1, 32 * t + 4 * h);
+            load_const(csh, lsh1, 32 * t + 4 * h);
+            bn_relu(a1[t], csc, csh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        layer_t<NT1, NT2, 0>(a2, a1, lw2, lsc2, lsh2, ring, lw3, lw3 + (size_t)NT2 * 256, lane, h);
+        constexpr int P2 = (((NT2 + 1) / 2) * NT1) & 1;
+        layer_max<NT2, NT3, P2>(a2, lw3, lsc3, lsh3, lmax, ring, lane, h, p.c3);
+
+        if (++in_ball == rpb) {                 // the ball is complete: its row leaves, the LDS row starts again from zero
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float *out = p.out + (size_t)ball * p.ldo;
+#pragma unroll
+            for (int ch = lane; ch < C; ch += 64) {
+                const int v = lmax[ch];
+                lmax[ch] = 0;
+                if (ch < p.c3) out[ch] = __int_as_float(v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            in_ball = 0;
+            ++ball;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The narrow stack of the first multi-scale level, (3 + cf) -> 32 -> 32 -> 64 + max, at its
 // own widths.  Padded to the 64-64-128 kernel it ran 200 MFMAs per 32 rows, three quarters
 // of them on zeros; here it is 4 + 16 + 32.  All its weights fit a lane's registers (one
@@ -1173,6 +1321,38 @@ __global__ void flipout_weights_kernel(int b, int cin, int cout, int layout, con
     }
 }
 
+// FPN_F32_SA=launch keeps the per-group kernel for the stacks over coordinates (a measurement switch; the
+// twin of the tests)
+inline bool sa_persistent_f32()
+{
+    const char *e = std::getenv("FPN_F32_SA");
+    return !(e && std::string(e) == "launch");
+}
+
+template <int NT1, int NT2, int NT3>
+int launch_sa_persist(const SaChainParams &p, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)(NT1 * NT2 + NT2 * NT3) * 256 * 16 + (2 * 32 * (NT1 + NT2 + NT3)) * 4 + kRegWaves * 32 * NT3 * 4;
+    static_assert(lds <= 160 * 1024 / 2, "two workgroups per CU must fit LDS");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+        return fail(FPN_E_LAUNCH, "sa_chain: cannot read the device's CU count");
+    const unsigned balls = (unsigned)(p.rows / p.ns);
+    unsigned wgs = std::min<unsigned>((unsigned)cus * 2, (balls + kRegWaves - 1) / kRegWaves);
+    if (wgs >= 8) wgs -= wgs % 8;               // whole rounds over the XCDs (logical_block)
+    const unsigned per_wave = (balls + wgs * kRegWaves - 1) / (wgs * kRegWaves);
+    const void *fn = p.pre ? reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, true>)
+                           : reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, false>);
+    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail(FPN_E_LAUNCH, "sa_chain: the device refuses %zu bytes of LDS per workgroup", lds);
+    if (p.pre)
+        hipLaunchKernelGGL((sa_persist_kernel<NT1, NT2, NT3, true>), dim3(wgs), dim3(64 * kRegWaves), lds, st, p, balls, per_wave);
+    else
+        hipLaunchKernelGGL((sa_persist_kernel<NT1, NT2, NT3, false>), dim3(wgs), dim3(64 * kRegWaves), lds, st, p, balls, per_wave);
+    return check_launch("fpn_sa_chain_f32");
+}
+
 template <int NJF, int NT1, int NT2, int NT3>
 int launch_sa_chain(const SaChainParams &p, hipStream_t st)
 {
@@ -1303,6 +1483,8 @@ static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int
         hipLaunchKernelGGL(sa_small_kernel, dim3(wgs), dim3(64 * kRegWaves), 0, st, p, groups, per_wave);
         return check_launch("fpn_sa_chain_f32");
     }
+    if (njf == 0 && t1 == 2 && t2 <= 3 && sa_persistent_f32() && p.rows < (1L << 31))
+        return t2 == 2 ? launch_sa_persist<2, 2, 4>(p, st) : launch_sa_persist<2, 3, 4>(p, st);
     if (njf == 0 && t1 == 4) return launch_sa_chain<0, 4, 4, 8>(p, st);
     if (njf == 0 && t2 == 2) return launch_sa_chain<0, 2, 2, 4>(p, st);
     if (njf == 0 && t2 == 3) return launch_sa_chain<0, 2, 3, 4>(p, st);

@@ -352,3 +352,39 @@ def test_fp_module_single_known_point(device, c1, c2, mlp):
     assert got[True].shape == (b, n, mlp[-1])
     close(got[True].cpu().numpy(), want)
     close(got[True].cpu().numpy(), got[False].cpu().numpy(), rtol=1e-5)
+
+
+def test_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
+    """fp32 set abstraction over coordinates whose layers fit LDS (64-64-128, 64-96-128): the
+    persistent kernel and the kernel launched per 32 samples (FPN_F32_SA=launch) give the
+    same bits - one to eight rounds per ball, 0 / 1 / 4 direct feature channels, ball counts
+    that leave waves and workgroups without work, and wide features entering as first-layer
+    products."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(11)
+    cases = [("msg", 3, 1024, 1, (64, [0.1, 0.2, 0.4], [32, 64, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]])),
+             ("ssg", 2, 512, 0, (5, 0.3, 32, [64, 96, 128])),
+             ("ssg", 1, 512, 4, (3, 0.3, 128, [64, 64, 128])),
+             ("ssg", 5, 700, 1, (129, 0.25, 256, [64, 64, 128])),
+             ("ssg", 40, 256, 0, (128, 0.3, 64, [64, 96, 128])),
+             ("msg", 3, 128, 320, (32, [0.4, 0.8], [64, 32], [[64, 64, 128], [64, 96, 128]]))]
+    for kind, b, n, cf, args in cases:
+        xyz = dev(rng.uniform(0, 1, (b, n, 3)).astype(np.float32), device)
+        pts = dev(rng.standard_normal((b, n, cf)).astype(np.float32), device) if cf else None
+        st = fresh_store(device, seed=6)
+        got = {}
+        for mode in ("persistent", "launch", "persistent"):
+            if mode == "launch":
+                monkeypatch.setenv("FPN_F32_SA", "launch")
+            else:
+                monkeypatch.delenv("FPN_F32_SA", raising=False)
+            with variables.use_store(st):
+                if kind == "msg":
+                    _, feat = U.pointnet_sa_module_msg(xyz, pts, *args, False, None, scope='s')
+                else:
+                    _, feat, _ = U.pointnet_sa_module(xyz, pts, *args, None, False, False, None, scope='s')
+            got[mode] = feat.clone()
+        assert len(st.__dict__.get("_sa_chain_cache", {})) >= 1, "fused kernel not taken"
+        assert torch.equal(got["persistent"], got["launch"]), (kind, b, args[0])
+        assert got["persistent"].abs().max() > 0
