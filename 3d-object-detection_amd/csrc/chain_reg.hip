@@ -964,20 +964,24 @@ __global__ __launch_bounds__(64 * kRegWaves, NJF == 0 ? 2 : 1) void sa_chain_ker
 // in the wave's own LDS row and the wave stores the finished row itself (no memory atomics,
 // no barrier after the set-up).  Same arithmetic as sa_chain_kernel, operation by operation.
 // ---------------------------------------------------------------------------
-template <int NT1, int NT2, int NT3, bool PRE>
-__global__ __launch_bounds__(64 * kRegWaves, 2) void sa_persist_kernel(const SaChainParams p, unsigned balls,
-                                                                       unsigned balls_per_wave)
+// W3LDS = false (128-128-256: 64 + 128 KiB of weights): only the second layer lies in LDS, the third layer's
+// chunks come from memory through the ring as in sa_chain_kernel; one workgroup per CU (the registers of
+// four accumulating tile sets and the next round's products do not fit two).
+template <int NT1, int NT2, int NT3, bool PRE, bool W3LDS = true>
+__global__ __launch_bounds__(64 * kRegWaves, W3LDS ? 2 : 1) void sa_persist_kernel(const SaChainParams p, unsigned balls,
+                                                                                   unsigned balls_per_wave)
 {
-    constexpr int C = 32 * NT3, W2 = NT1 * NT2 * 256, W3 = NT2 * NT3 * 256;     // float4 per layer
+    constexpr int C = 32 * NT3, W2 = NT1 * NT2 * 256, W3 = W3LDS ? NT2 * NT3 * 256 : 0;     // float4 per layer in LDS
     extern __shared__ float4 sa_persist_lds[];
-    float4 *lw2 = sa_persist_lds, *lw3 = lw2 + W2;
-    float *lsc2 = reinterpret_cast<float *>(lw3 + W3), *lsh2 = lsc2 + 32 * NT2, *lsc3 = lsh2 + 32 * NT2, *lsh3 = lsc3 + C;
+    float4 *lw2 = sa_persist_lds;
+    const float4 *lw3 = W3LDS ? lw2 + W2 : p.w3;
+    float *lsc2 = reinterpret_cast<float *>(lw2 + W2 + W3), *lsh2 = lsc2 + 32 * NT2, *lsc3 = lsh2 + 32 * NT2, *lsh3 = lsc3 + C;
     float *lsc1 = lsh3 + C, *lsh1 = lsc1 + 32 * NT1;
     int *lmax = reinterpret_cast<int *>(lsh1 + 32 * NT1) + (threadIdx.x >> 6) * C;
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
     for (int i = threadIdx.x; i < W2; i += 64 * kRegWaves) lw2[i] = p.w2[i];
-    for (int i = threadIdx.x; i < W3; i += 64 * kRegWaves) lw3[i] = p.w3[i];
+    for (int i = threadIdx.x; i < W3; i += 64 * kRegWaves) lw2[W2 + i] = p.w3[i];
     for (int i = threadIdx.x; i < 32 * NT2; i += 64 * kRegWaves) {
         lsc2[i] = p.sc2[i];
         lsh2[i] = p.sh2[i];
@@ -1329,27 +1333,31 @@ inline bool sa_persistent_f32()
     return !(e && std::string(e) == "launch");
 }
 
-template <int NT1, int NT2, int NT3>
+template <int NT1, int NT2, int NT3, bool W3LDS = true>
 int launch_sa_persist(const SaChainParams &p, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)(NT1 * NT2 + NT2 * NT3) * 256 * 16 + (2 * 32 * (NT1 + NT2 + NT3)) * 4 + kRegWaves * 32 * NT3 * 4;
-    static_assert(lds <= 160 * 1024 / 2, "two workgroups per CU must fit LDS");
+    constexpr size_t lds = (size_t)(NT1 * NT2 + (W3LDS ? NT2 * NT3 : 0)) * 256 * 16 + (2 * 32 * (NT1 + NT2 + NT3)) * 4 +
+                           kRegWaves * 32 * NT3 * 4;
+    constexpr int per_cu = W3LDS ? 2 : 1;       // workgroups per CU (the kernel's launch bounds)
+    static_assert(lds <= 160 * 1024 / per_cu, "the workgroups of a CU must fit LDS");
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         cus < 1)
         return fail(FPN_E_LAUNCH, "sa_chain: cannot read the device's CU count");
     const unsigned balls = (unsigned)(p.rows / p.ns);
-    unsigned wgs = std::min<unsigned>((unsigned)cus * 2, (balls + kRegWaves - 1) / kRegWaves);
+    unsigned wgs = std::min<unsigned>((unsigned)cus * per_cu, (balls + kRegWaves - 1) / kRegWaves);
     if (wgs >= 8) wgs -= wgs % 8;               // whole rounds over the XCDs (logical_block)
     const unsigned per_wave = (balls + wgs * kRegWaves - 1) / (wgs * kRegWaves);
-    const void *fn = p.pre ? reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, true>)
-                           : reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, false>);
+    const void *fn = p.pre ? reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, true, W3LDS>)
+                           : reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, false, W3LDS>);
     if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return fail(FPN_E_LAUNCH, "sa_chain: the device refuses %zu bytes of LDS per workgroup", lds);
     if (p.pre)
-        hipLaunchKernelGGL((sa_persist_kernel<NT1, NT2, NT3, true>), dim3(wgs), dim3(64 * kRegWaves), lds, st, p, balls, per_wave);
+        hipLaunchKernelGGL((sa_persist_kernel<NT1, NT2, NT3, true, W3LDS>), dim3(wgs), dim3(64 * kRegWaves), lds, st, p, balls,
+                           per_wave);
     else
-        hipLaunchKernelGGL((sa_persist_kernel<NT1, NT2, NT3, false>), dim3(wgs), dim3(64 * kRegWaves), lds, st, p, balls, per_wave);
+        hipLaunchKernelGGL((sa_persist_kernel<NT1, NT2, NT3, false, W3LDS>), dim3(wgs), dim3(64 * kRegWaves), lds, st, p, balls,
+                           per_wave);
     return check_launch("fpn_sa_chain_f32");
 }
 
@@ -1485,6 +1493,7 @@ static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int
     }
     if (njf == 0 && t1 == 2 && t2 <= 3 && sa_persistent_f32() && p.rows < (1L << 31))
         return t2 == 2 ? launch_sa_persist<2, 2, 4>(p, st) : launch_sa_persist<2, 3, 4>(p, st);
+    if (njf == 0 && t1 == 4 && sa_persistent_f32() && p.rows < (1L << 31)) return launch_sa_persist<4, 4, 8, false>(p, st);
     if (njf == 0 && t1 == 4) return launch_sa_chain<0, 4, 4, 8>(p, st);
     if (njf == 0 && t2 == 2) return launch_sa_chain<0, 2, 2, 4>(p, st);
     if (njf == 0 && t2 == 3) return launch_sa_chain<0, 2, 3, 4>(p, st);

@@ -355,7 +355,8 @@ def test_fp_module_single_known_point(device, c1, c2, mlp):
 
 
 def test_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
-    """fp32 set abstraction over coordinates whose layers fit LDS (64-64-128, 64-96-128): the
+    """fp32 set abstraction over coordinates (64-64-128, 64-96-128 with both layers in LDS,
+    128-128-256 with the second): the
     persistent kernel and the kernel launched per 32 samples (FPN_F32_SA=launch) give the
     same bits - one to eight rounds per ball, 0 / 1 / 4 direct feature channels, ball counts
     that leave waves and workgroups without work, and wide features entering as first-layer
@@ -368,7 +369,10 @@ def test_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
              ("ssg", 1, 512, 4, (3, 0.3, 128, [64, 64, 128])),
              ("ssg", 5, 700, 1, (129, 0.25, 256, [64, 64, 128])),
              ("ssg", 40, 256, 0, (128, 0.3, 64, [64, 96, 128])),
-             ("msg", 3, 128, 320, (32, [0.4, 0.8], [64, 32], [[64, 64, 128], [64, 96, 128]]))]
+             ("msg", 3, 128, 320, (32, [0.4, 0.8], [64, 32], [[64, 64, 128], [64, 96, 128]])),
+             # 128-128-256: the second layer from LDS, the third from memory
+             ("msg", 3, 128, 320, (32, [0.4, 0.8, 1.6], [64, 64, 128], [[64, 64, 128], [128, 128, 256], [128, 128, 256]])),
+             ("ssg", 2, 128, 128, (7, 0.5, 32, [128, 128, 256]))]
     for kind, b, n, cf, args in cases:
         xyz = dev(rng.uniform(0, 1, (b, n, 3)).astype(np.float32), device)
         pts = dev(rng.standard_normal((b, n, cf)).astype(np.float32), device) if cf else None
