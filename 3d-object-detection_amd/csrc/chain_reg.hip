@@ -1325,6 +1325,120 @@ __global__ void flipout_weights_kernel(int b, int cin, int cout, int layout, con
     }
 }
 
+// ---------------------------------------------------------------------------
+// The per-point head with the interpolated features' share of its first layer taken out:
+// three_interpolate is linear (weights that sum to one over three known points), and so is
+// the first layer before its batch norm and ReLU, so the 128 known points of a frustum go
+// through their rows of W1 ONCE and the products are interpolated to the 2048 query points
+// (pre), instead of interpolating the features and multiplying 2048 rows.  The kernel starts
+// the first layer from pre, adds the point's own (at most 8) channels, and runs the two
+// remaining 128 x 128 layers and the final 128 -> 2 product.  Persistent: both layers'
+// chunks (128 KiB) and all constants lie in LDS, a wave walks consecutive groups of 32
+// points with the next group's rows in flight.
+// ---------------------------------------------------------------------------
+struct FpHeadPreParams {
+    long rows;
+    int cb;
+    const float *pre, *xb;                      // (rows,128) first-layer products, (rows,cb)
+    const float *w1b, *sc1, *sh1;               // (cb,128) row-major: the own channels' rows of W1
+    const float4 *w2; const float *sc2, *sh2;   // chunked (128,128)
+    const float4 *w3; const float *sc3, *sh3;
+    const float *w4, *b4;                       // (128,2) row-major, (2)
+    float *logits;                              // (rows,2)
+};
+
+__global__ __launch_bounds__(64 * kRegWaves, 1) void fp_head_pre_kernel(const FpHeadPreParams p, unsigned rounds,
+                                                                        unsigned rounds_per_wave)
+{
+    constexpr int W = 4 * 4 * 256;              // float4 per 128 x 128 layer
+    extern __shared__ float4 fp_head_pre_lds[];
+    float4 *lw2 = fp_head_pre_lds, *lw3 = lw2 + W;
+    float *lc = reinterpret_cast<float *>(lw3 + W);     // sc1, sh1, sc2, sh2, sc3, sh3 (128 each), w4 (256)
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    for (int i = threadIdx.x; i < W; i += 64 * kRegWaves) {
+        lw2[i] = p.w2[i];
+        lw3[i] = p.w3[i];
+    }
+    for (int i = threadIdx.x; i < 128; i += 64 * kRegWaves) {
+        lc[i] = p.sc1[i];       lc[128 + i] = p.sh1[i];
+        lc[256 + i] = p.sc2[i]; lc[384 + i] = p.sh2[i];
+        lc[512 + i] = p.sc3[i]; lc[640 + i] = p.sh3[i];
+        lc[768 + i] = p.w4[i];  lc[896 + i] = p.w4[128 + i];
+    }
+    __syncthreads();
+    const unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * kRegWaves + (threadIdx.x >> 6));
+    const unsigned r0 = gw * rounds_per_wave, r1 = min(rounds, r0 + rounds_per_wave);
+    if (r0 >= r1) return;
+    const float b40 = p.b4[0], b41 = p.b4[1];
+    float wv[4][4];             // the own channels' weights: tile t, MFMA step s = channel 2 s + h
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wv[t][s] = 2 * s + h < p.cb ? p.w1b[(2 * s + h) * 128 + 32 * t + (lane & 31)] : 0.f;
+
+    float4 pr[4][4];
+    float xr[4];
+    auto load_in = [&](unsigned r) {
+        const size_t row = (size_t)r * 32 + pt;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pr[t][i] = *reinterpret_cast<const float4 *>(p.pre + row * 128 + 32 * t + 8 * i + 4 * h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xr[s] = 2 * s + h < p.cb ? p.xb[row * p.cb + 2 * s + h] : 0.f;
+    };
+    load_in(r0);
+    WChunk ring[4];
+#pragma unroll 1
+    for (unsigned r = r0; r < r1; ++r) {
+        floatx16 a1[4], a2[4], a3[4];
+        float x[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x[s] = xr[s];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a1[t][4 * i + 0] = pr[t][i].x; a1[t][4 * i + 1] = pr[t][i].y;
+                a1[t][4 * i + 2] = pr[t][i].z; a1[t][4 * i + 3] = pr[t][i].w;
+            }
+        load_in(min(r + 1, r1 - 1));
+        load_chunk(ring[0], lw2, lane);
+        load_chunk(ring[1], lw2 + 4 * 256, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t][s], x[s], a1[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            TileConst csc, csh;
+            load_const(csc, lc, 32 * t + 4 * h);
+            load_const(csh, lc + 128, 32 * t + 4 * h);
+            bn_relu(a1[t], csc, csh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        layer_t<4, 4>(a2, a1, lw2, lc + 256, lc + 384, ring, lw3, lw3 + 4 * 256, lane, h);
+        layer_t<4, 4>(a3, a2, lw3, lc + 512, lc + 640, ring, lw2, lw2 + 4 * 256, lane, h);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 *w = reinterpret_cast<const float4 *>(lc + 768 + (32 * j + 8 * q + 4 * h) * 2);
+                const float4 wa = w[0], wb = w[1];
+                s0 = fmaf(a3[j][4 * q + 0], wa.x, s0); s1 = fmaf(a3[j][4 * q + 0], wa.y, s1);
+                s0 = fmaf(a3[j][4 * q + 1], wa.z, s0); s1 = fmaf(a3[j][4 * q + 1], wa.w, s1);
+                s0 = fmaf(a3[j][4 * q + 2], wb.x, s0); s1 = fmaf(a3[j][4 * q + 2], wb.y, s1);
+                s0 = fmaf(a3[j][4 * q + 3], wb.z, s0); s1 = fmaf(a3[j][4 * q + 3], wb.w, s1);
+            }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (h == 0) *reinterpret_cast<float2 *>(p.logits + ((size_t)r * 32 + pt) * 2) = make_float2(s0 + b40, s1 + b41);
+    }
+}
+
 // FPN_F32_SA=launch keeps the per-group kernel for the stacks over coordinates (a measurement switch; the
 // twin of the tests)
 inline bool sa_persistent_f32()
@@ -1539,6 +1653,37 @@ int fpn_fp_head_chain_f32(long rows, int ca, int cb, const float *xa, const floa
     hipLaunchKernelGGL(fp_head_reg_kernel<4>, dim3((unsigned)((waves + kRegWaves - 1) / kRegWaves)), dim3(64 * kRegWaves), 0,
                        as_stream(stream), p);
     return check_launch("fpn_fp_head_chain_f32");
+}
+
+int fpn_fp_head_chain_pre_f32(long rows, int cb, const float *pre, const float *xb, const float *const *layers,
+                              float *logits, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && rows % 32 == 0 && rows / 32 < (1L << 31), "fp_head_chain_pre: rows (%ld) must be a multiple of 32", rows);
+    FPN_REQUIRE(cb >= 0 && cb <= 8, "fp_head_chain_pre: at most 8 own channels per point (%d)", cb);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(pre && (cb == 0 || xb) && layers && logits, "fp_head_chain_pre: null pointer");
+    for (int i = (cb ? 0 : 1); i < 11; ++i) FPN_REQUIRE(layers[i], "fp_head_chain_pre: layer parameter %d is null", i);
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(pre) & 15) == 0, "fp_head_chain_pre: pre must be 16-byte aligned");
+    FpHeadPreParams p{};
+    p.rows = rows; p.cb = cb; p.pre = pre; p.xb = cb ? xb : pre;
+    p.w1b = cb ? layers[0] : layers[1]; p.sc1 = layers[1]; p.sh1 = layers[2];
+    p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
+    p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
+    p.w4 = layers[9]; p.b4 = layers[10];
+    p.logits = logits;
+    constexpr size_t lds = (size_t)2 * 4 * 4 * 256 * 16 + 1024 * 4;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+        return fail(FPN_E_LAUNCH, "fp_head_chain_pre: cannot read the device's CU count");
+    const unsigned rounds = (unsigned)(rows / 32);
+    const unsigned wgs = std::min<unsigned>((unsigned)cus, (rounds + kRegWaves - 1) / kRegWaves);
+    const unsigned per_wave = (rounds + wgs * kRegWaves - 1) / (wgs * kRegWaves);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_head_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return fail(FPN_E_LAUNCH, "fp_head_chain_pre: the device refuses %zu bytes of LDS per workgroup", lds);
+    hipLaunchKernelGGL(fp_head_pre_kernel, dim3(wgs), dim3(64 * kRegWaves), lds, as_stream(stream), p, rounds, per_wave);
+    return check_launch("fpn_fp_head_chain_pre_f32");
 }
 
 int fpn_v1_seg_head_f32(long rows, int n, int cpc, const float *pc, const float *const *layers,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class FpnError(RuntimeError):
@@ -73,6 +73,7 @@ SIGNATURES = {
     "fpn_sa_chain_bf16p": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_sa_pack_features_bf16": [_l, _i, _vp, _vp, _vp],
     "fpn_fp_head_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "fpn_fp_head_chain_pre_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_fp_head_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_fp_head_chain_bf16x": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],

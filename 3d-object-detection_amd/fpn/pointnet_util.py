@@ -493,7 +493,7 @@ def _fp_head_plan(store, names, cb, bn):
     """Weights of the fused feature-propagation head in the form fpn_fp_head_chain_*
     reads them; cached on the store until its variables change."""
     cache = store.__dict__.setdefault("_fp_head_cache", {})
-    key = (names[0], cb, SA_PRECISION)
+    key = (names[0], cb, SA_PRECISION, HOIST_FEATURES)
     hit = cache.get(key)
     if hit is not None and hit["version"] == store.version:
         return hit
@@ -519,6 +519,12 @@ def _fp_head_plan(store, names, cb, bn):
             tensors += [ops.tile_weights_reg(w, 0), sc, sh]
         tensors += [w4.contiguous(), b4]
         plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors)}
+        if HOIST_FEATURES and cb <= 8:
+            # the interpolated features' rows of the first layer meet the KNOWN points (fpn_fp_head_chain_pre_f32)
+            w1a = params[0][0][:128].contiguous()
+            w1b = params[0][0][128:128 + cb].contiguous() if cb else scales[0]
+            pre_tensors = [w1b] + tensors[1:]
+            plan["pre"] = {"w1a": w1a, "tensors": pre_tensors, "table": ops.pointer_table(pre_tensors)}
     cache[key] = plan
     return plan
 
@@ -546,11 +552,6 @@ def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, 
     store = variables.get_default_store()
     with variables.variable_scope(scope):
         names = [variables.scoped('conv_0'), variables.scoped('conv_1')]
-        # the bf16 kernel rounds its inputs to bf16 as it reads them: rounded on the way OUT of the
-        # interpolation instead, the same values cross memory in half the bytes (INTERP_BF16)
-        half = SA_PRECISION == "bf16" and INTERP_BF16
-        interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous(),
-                                            out_dtype=torch.bfloat16 if half else torch.float32)   # :210-215
     names += [variables.scoped(head_scope), variables.scoped(out_scope)]
     plan = _fp_head_plan(store, names, cb, bn)
     rows = b * n
@@ -558,6 +559,26 @@ def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, 
     xb = None if points1 is None else points1.contiguous()
     lib = _lib.load()
     obs = ops.launch_observer
+    if "pre" in plan:
+        # interpolation and the first layer (before its batch norm) are both linear: the known points go through
+        # their rows of W1 once, the PRODUCTS are interpolated (:210-215 after :222-226 for those rows)
+        m = xyz2.shape[1]
+        known = ops.shared_mlp(points2.contiguous().reshape(b * m, 128), plan["pre"]["w1a"], None, None, relu=False)
+        pre = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), known.reshape(b, m, 128))
+        tok = obs.begin("fp_head_chain_pre", rows, 0, 0, macs=rows * (cb * 128 + 2 * 128 * 128 + 128 * 2)) \
+            if obs is not None else None
+        with torch.cuda.device(xyz1.device):
+            _lib.check(lib.fpn_fp_head_chain_pre_f32(rows, cb, _lib.ptr(pre), _lib.ptr(xb), plan["pre"]["table"],
+                                                     _lib.ptr(logits), _lib.stream_of(xyz1)))
+        if obs is not None:
+            obs.end(tok)
+        return logits
+    with variables.variable_scope(scope):
+        # the bf16 kernel rounds its inputs to bf16 as it reads them: rounded on the way OUT of the
+        # interpolation instead, the same values cross memory in half the bytes (INTERP_BF16)
+        half = SA_PRECISION == "bf16" and INTERP_BF16
+        interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous(),
+                                            out_dtype=torch.bfloat16 if half else torch.float32)   # :210-215
     tok = obs.begin("fp_head_chain_bf16" if "stream" in plan else "fp_head_chain", rows, 0, 0,
                     macs=rows * ((128 + cb) * 128 + 2 * 128 * 128 + 128 * 2)) if obs is not None else None
     with torch.cuda.device(xyz1.device):

@@ -437,6 +437,16 @@ int fpn_sa_chain_pre_f32(int b, int n, int m, int ns, int cf, int c1, int c2, in
  */
 int fpn_fp_head_chain_f32(long rows, int ca, int cb, const float *xa, const float *xb,
                           const float *const *layers, float *logits, void *stream);
+/* The same head with the interpolated features' share of the first layer as per-point
+ * products: three_interpolate (models/pointnet_util.py:210-215) and the first convolution
+ * before its batch norm (:222-226) are both linear, so the caller multiplies the KNOWN points'
+ * features with their 128 rows of W1 once (no scale, no shift), interpolates those products to
+ * the query points - pre (rows,128), 16-byte aligned - and this kernel starts the first layer
+ * from them and adds the own channels' part.  cb <= 8.  layers: 11 device pointers {w1b,
+ * scale1, shift1, w2, scale2, shift2, w3, scale3, shift3, w4, bias4}: w1b (cb,128) row-major =
+ * the own channels' rows of W1 (ignored when cb == 0), the rest as above. */
+int fpn_fp_head_chain_pre_f32(long rows, int cb, const float *pre, const float *xb,
+                              const float *const *layers, float *logits, void *stream);
 
 /*
  * The same layer chains on the bf16 matrix instruction (fp32 accumulation): the
