@@ -1513,6 +1513,116 @@ __global__ __launch_bounds__(64 * kWaves, 1) void fp_head_lds_bf16_kernel(const 
     }
 }
 
+// The head with the interpolated features' share of its first layer taken out (as
+// fp_head_pre_kernel of chain_reg.hip): the known points' features meet their rows of W1 once,
+// the PRODUCTS are interpolated (pre, bf16 rows, scaled like the layer) and start the first
+// layer here; the point's own channels (at most 8) add their part through the split-operand
+// first layer; then the two remaining 128 x 128 layers (stream: 16 units, in LDS) and the
+// final 128 -> 2 product.  Persistent, as fp_head_lds_bf16_kernel.
+struct FpHeadPreParams {
+    long rows;
+    int cb;
+    const __bf16 *pre;                  // (rows,128)
+    const float *xb;                    // (rows,cb)
+    const float *w1b, *sc1, *sh1;       // (cb,128) fp32: the own channels' rows of W1
+    const bf16x8 *ws;                   // layer 2, layer 3
+    const float *sh2, *sh3, *w4, *b4;
+    float *logits;
+};
+
+template <int NP>
+__global__ __launch_bounds__(64 * kWaves, 1) void fp_head_pre_bf16_kernel(const FpHeadPreParams p, unsigned rounds,
+                                                                          unsigned rounds_per_wave)
+{
+    constexpr int U2 = 8, U = 2 * U2;
+    extern __shared__ bf16x8 fp_head_pre_lds[];
+    bf16x8 *wl = fp_head_pre_lds;                                       // U + kLdsAhead units
+    float *lsh = reinterpret_cast<float *>(wl + (U + kLdsAhead) * kUnitVecs);   // shifts of layers 2 and 3
+    float *lw4 = lsh + 2 * 128;                                         // (128, 2)
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    for (int i = threadIdx.x; i < U * kUnitVecs; i += 64 * kWaves) wl[i] = p.ws[i];
+    for (int i = threadIdx.x; i < kLdsAhead * kUnitVecs; i += 64 * kWaves) wl[U * kUnitVecs + i] = p.ws[i];
+    for (int i = threadIdx.x; i < 128; i += 64 * kWaves) {
+        lsh[i] = p.sh2[i];
+        lsh[128 + i] = p.sh3[i];
+        lw4[i] = p.w4[i];
+        lw4[128 + i] = p.w4[128 + i];
+    }
+    __syncthreads();
+    const unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (threadIdx.x >> 6));
+    const unsigned r0 = gw * rounds_per_wave, r1 = min(rounds, r0 + rounds_per_wave);
+    if (r0 >= r1) return;
+    const float b40 = p.b4[0], b41 = p.b4[1];
+    FirstLayer<4, 8> first;
+    first.load(p.w1b, p.cb, p.sc1, p.sh1, lane, h);
+
+    bf16x4 rp[NP][16];          // a group's rows of products as they lie in memory: vector 4 t + q = channels 32 t + 8 q + 4 h ..
+    float rx[NP][8];
+    auto load_in = [&](unsigned r) {
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const size_t row = (size_t)r * (32 * NP) + 32 * g + pt;
+            const bf16x4 *src = reinterpret_cast<const bf16x4 *>(p.pre + row * 128);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rp[g][i] = src[2 * i + h];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rx[g][k] = k < p.cb ? p.xb[row * p.cb + k] : 0.f;
+        }
+    };
+    load_in(r0);
+
+    LdsFeed feed;
+    feed.start(p.ws, lane, wl);
+    const bf16x8 *ws = p.ws;
+#pragma unroll 1
+    for (unsigned r = r0; r < r1; ++r) {
+        float x[NP][8];
+        floatx16 init[NP][4];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[g][k] = rx[g][k];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) init[g][i >> 2][4 * (i & 3) + e] = (float)rp[g][i][e];
+        }
+        load_in(min(r + 1, r1 - 1));
+        TileConst c2[2], c3[2];
+        load_const(c2[0], lsh, 4 * h);
+        load_const(c2[1], lsh, 32 + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
+
+        Act a1[NP][4], a2[NP][4];
+        floatx16 a3[NP][4];
+        first.apply(a1, x, h, init);
+        load_const(c3[0], lsh + 128, 4 * h);
+        load_const(c3[1], lsh + 128, 32 + 4 * h);
+        layer_t_from<NP, 4, 4, 0>(a2, a1, ws, lsh, feed, h, c2);
+        layer_t_from<NP, 4, 4, U2 % kRing>(a3, a2, ws + U2 * kUnitVecs, lsh + 128, feed, h, c3);
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 *w = reinterpret_cast<const float4 *>(lw4 + (32 * j + 8 * q + 4 * h) * 2);
+                    const float4 wa = w[0], wb = w[1];
+                    s0 = fmaf(a3[g][j][4 * q + 0], wa.x, s0); s1 = fmaf(a3[g][j][4 * q + 0], wa.y, s1);
+                    s0 = fmaf(a3[g][j][4 * q + 1], wa.z, s0); s1 = fmaf(a3[g][j][4 * q + 1], wa.w, s1);
+                    s0 = fmaf(a3[g][j][4 * q + 2], wb.x, s0); s1 = fmaf(a3[g][j][4 * q + 2], wb.y, s1);
+                    s0 = fmaf(a3[g][j][4 * q + 3], wb.z, s0); s1 = fmaf(a3[g][j][4 * q + 3], wb.w, s1);
+                }
+            s0 += __shfl_xor(s0, 32);
+            s1 += __shfl_xor(s1, 32);
+            if (h == 0)
+                *reinterpret_cast<float2 *>(p.logits + ((size_t)r * (32 * NP) + 32 * g + pt) * 2) = make_float2(s0 + b40, s1 + b41);
+        }
+    }
+}
+
 // Point features (points, cf) fp32, cf a multiple of 32 -> the operand fragments a lane of the
 // set-abstraction kernel holds for that point: vector ((2 t + s) * 2 + h) of a point = the 8
 // channels 32 t + 16 s + 8 (e >> 2) + 4 h + (e & 3), e = 0..7, rounded to bf16.
@@ -1871,6 +1981,41 @@ int fpn_fp_head_chain_bf16x(long rows, int ca, int cb, const void *xa_bf16, cons
                             const float *const *consts, float *logits, void *stream)
 {
     return fp_head_chain_bf16(rows, ca, cb, xa_bf16, 1, xb, wstream, consts, logits, stream);
+}
+
+int fpn_fp_head_chain_pre_bf16(long rows, int cb, const void *pre_bf16, const float *xb, const void *wstream,
+                               const float *const *consts, float *logits, void *stream)
+{
+    FPN_REQUIRE(rows >= 0 && rows % 32 == 0 && rows / 32 < (1L << 31), "fp_head_chain_pre_bf16: rows (%ld) must be a multiple of 32", rows);
+    FPN_REQUIRE(cb >= 0 && cb <= 8, "fp_head_chain_pre_bf16: at most 8 own channels per point (%d)", cb);
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(pre_bf16 && (cb == 0 || xb) && wstream && consts && logits, "fp_head_chain_pre_bf16: null pointer");
+    for (int i = 0; i < 7; ++i) FPN_REQUIRE(consts[i], "fp_head_chain_pre_bf16: constant %d is null", i);
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(pre_bf16) & 15) == 0, "fp_head_chain_pre_bf16: pre must be 16-byte aligned");
+    FpHeadPreParams p{};
+    p.rows = rows; p.cb = cb; p.pre = static_cast<const __bf16 *>(pre_bf16); p.xb = cb ? xb : logits;
+    p.w1b = consts[0]; p.sc1 = consts[1]; p.sh1 = consts[2];
+    p.ws = reinterpret_cast<const bf16x8 *>(wstream);
+    p.sh2 = consts[3]; p.sh3 = consts[4]; p.w4 = consts[5]; p.b4 = consts[6];
+    p.logits = logits;
+    constexpr size_t lds = (size_t)(16 + kLdsAhead) * kUnitVecs * 16 + (2 * 128 + 256) * 4;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+        return fail(FPN_E_LAUNCH, "fp_head_chain_pre_bf16: cannot read the device's CU count");
+    const int np = rows % 64 == 0 ? 2 : 1;
+    const unsigned rounds = (unsigned)(rows / (32 * np));
+    const unsigned groups = std::min<unsigned>((unsigned)cus, (rounds + kWaves - 1) / kWaves);
+    const unsigned per_wave = (rounds + groups * kWaves - 1) / (groups * kWaves);
+    const void *fn = np == 2 ? reinterpret_cast<const void *>(&fp_head_pre_bf16_kernel<2>)
+                             : reinterpret_cast<const void *>(&fp_head_pre_bf16_kernel<1>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail(FPN_E_LAUNCH, "fp_head_chain_pre_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
+    if (np == 2)
+        hipLaunchKernelGGL(fp_head_pre_bf16_kernel<2>, dim3(groups), dim3(64 * kWaves), lds, as_stream(stream), p, rounds, per_wave);
+    else
+        hipLaunchKernelGGL(fp_head_pre_bf16_kernel<1>, dim3(groups), dim3(64 * kWaves), lds, as_stream(stream), p, rounds, per_wave);
+    return check_launch("fpn_fp_head_chain_pre_bf16");
 }
 
 int fpn_sa_pack_features_bf16(long points, int cf, const float *feat, void *packed, void *stream)

@@ -74,6 +74,7 @@ SIGNATURES = {
     "fpn_sa_pack_features_bf16": [_l, _i, _vp, _vp, _vp],
     "fpn_fp_head_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_fp_head_chain_pre_f32": [_l, _i, _vp, _vp, _vp, _vp, _vp],
+    "fpn_fp_head_chain_pre_bf16": [_l, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_fp_head_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_fp_head_chain_bf16x": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_mc_statistics": [_i, _i, _vp, _vp, _vp, _vp],

@@ -493,7 +493,7 @@ def _fp_head_plan(store, names, cb, bn):
     """Weights of the fused feature-propagation head in the form fpn_fp_head_chain_*
     reads them; cached on the store until its variables change."""
     cache = store.__dict__.setdefault("_fp_head_cache", {})
-    key = (names[0], cb, SA_PRECISION, HOIST_FEATURES)
+    key = (names[0], cb, SA_PRECISION, HOIST_FEATURES, INTERP_BF16)
     hit = cache.get(key)
     if hit is not None and hit["version"] == store.version:
         return hit
@@ -513,6 +513,14 @@ def _fp_head_plan(store, names, cb, bn):
         stream = ops.chain_stream_bf16(list(zip(ws, scales)))
         tensors = shifts + [w4.contiguous(), b4]
         plan = {"version": version, "tensors": tensors, "table": ops.pointer_table(tensors), "stream": stream}
+        if HOIST_FEATURES and cb <= 8 and INTERP_BF16:
+            # the interpolated features' rows of the first layer meet the KNOWN points (fpn_fp_head_chain_pre_bf16)
+            w1a = params[0][0][:128].contiguous()
+            w1b = params[0][0][128:128 + cb].contiguous() if cb else scales[0]
+            pre_tensors = [w1b, scales[0], shifts[0], shifts[1], shifts[2], w4.contiguous(), b4]
+            plan["pre"] = {"w1a": w1a, "w1a_bf16": ops.pack_mlp_bf16(w1a), "scale": scales[0], "tensors": pre_tensors,
+                           "table": ops.pointer_table(pre_tensors),
+                           "stream": ops.chain_stream_bf16(list(zip(ws[1:], scales[1:])))}
     else:
         tensors = []
         for w, sc, sh in zip(ws, scales, shifts):
@@ -563,13 +571,21 @@ def pointnet_fp_module_with_head(xyz1, xyz2, points1, points2, mlp, head_width, 
         # interpolation and the first layer (before its batch norm) are both linear: the known points go through
         # their rows of W1 once, the PRODUCTS are interpolated (:210-215 after :222-226 for those rows)
         m = xyz2.shape[1]
-        known = ops.shared_mlp(points2.contiguous().reshape(b * m, 128), plan["pre"]["w1a"], None, None, relu=False)
-        pre = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), known.reshape(b, m, 128))
-        tok = obs.begin("fp_head_chain_pre", rows, 0, 0, macs=rows * (cb * 128 + 2 * 128 * 128 + 128 * 2)) \
-            if obs is not None else None
+        hp = plan["pre"]
+        bf16 = "stream" in hp
+        known = ops.shared_mlp(points2.contiguous().reshape(b * m, 128), hp["w1a"], hp["scale"] if bf16 else None, None,
+                               relu=False, wt_bf16=hp.get("w1a_bf16"))
+        pre = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), known.reshape(b, m, 128),
+                                   out_dtype=torch.bfloat16 if bf16 else torch.float32)
+        tok = obs.begin("fp_head_chain_pre" + ("_bf16" if bf16 else ""), rows, 0, 0,
+                        macs=rows * (cb * 128 + 2 * 128 * 128 + 128 * 2)) if obs is not None else None
         with torch.cuda.device(xyz1.device):
-            _lib.check(lib.fpn_fp_head_chain_pre_f32(rows, cb, _lib.ptr(pre), _lib.ptr(xb), plan["pre"]["table"],
-                                                     _lib.ptr(logits), _lib.stream_of(xyz1)))
+            if bf16:
+                _lib.check(lib.fpn_fp_head_chain_pre_bf16(rows, cb, _lib.ptr(pre), _lib.ptr(xb), _lib.ptr(hp["stream"]),
+                                                          hp["table"], _lib.ptr(logits), _lib.stream_of(xyz1)))
+            else:
+                _lib.check(lib.fpn_fp_head_chain_pre_f32(rows, cb, _lib.ptr(pre), _lib.ptr(xb), hp["table"],
+                                                         _lib.ptr(logits), _lib.stream_of(xyz1)))
         if obs is not None:
             obs.end(tok)
         return logits

@@ -533,6 +533,13 @@ int fpn_sa_chain_bf16p(int b, int n, int m, int ns, int cf, int c1, int c2, int 
                        const float *new_xyz, const void *feat_packed, const int *idx,
                        const void *wstream, const float *const *consts, float *out, int ldo,
                        int c3_valid, void *stream);
+/* fpn_fp_head_chain_pre_f32 on bf16 operands: pre (rows,128) bf16 = the interpolated products
+ * of the known points' features with W1[their rows] . diag(scale1) (fpn_shared_mlp_bf16 then
+ * fpn_three_nn_interpolate_bf16); stream: layer 2, layer 3; consts {w1b (cb,128) fp32, scale1,
+ * shift1, shift2, shift3, w4 (128,2), bias4}; cb <= 8. */
+int fpn_fp_head_chain_pre_bf16(long rows, int cb, const void *pre_bf16, const float *xb,
+                               const void *wstream, const float *const *consts, float *logits,
+                               void *stream);
 /* fpn_fp_head_chain_f32 in bf16: stream: layer 1 (the padded (160,128) matrix), layer 2,
  * layer 3; consts {shift1, shift2, shift3, w4 (128,2) fp32, bias4}. */
 int fpn_fp_head_chain_bf16(long rows, int ca, int cb, const float *xa, const float *xb,

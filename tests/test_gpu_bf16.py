@@ -351,12 +351,13 @@ def test_bf16_interpolation_output_feeds_the_head_bit_for_bit(device):
     st = variables.VariableStore(device, seed=2)
     got = {}
     for flag in (True, False, True):
-        U.SA_PRECISION, U.INTERP_BF16 = "bf16", flag
+        # (the head that takes interpolated FEATURES: not the form that interpolates first-layer products)
+        U.SA_PRECISION, U.INTERP_BF16, U.HOIST_FEATURES = "bf16", flag, False
         try:
             with variables.use_store(st):
                 got[flag] = M2.get_model(dev(pc, device), dev(oh, device), False)["mask_logits"].clone()
         finally:
-            U.SA_PRECISION, U.INTERP_BF16 = "fp32", True
+            U.SA_PRECISION, U.INTERP_BF16, U.HOIST_FEATURES = "fp32", True, True
     assert torch.equal(got[True], got[False])
 
 
@@ -462,13 +463,13 @@ def test_bf16_persistent_head_bit_for_bit(device, monkeypatch, b, n, cb):
             monkeypatch.setenv("FPN_BF16_SA", "launch")
         else:
             monkeypatch.delenv("FPN_BF16_SA", raising=False)
-        U.SA_PRECISION = "bf16"
+        U.SA_PRECISION, U.HOIST_FEATURES = "bf16", False     # (the head that takes interpolated features)
         try:
             with variables.use_store(st):
                 got[mode] = U.pointnet_fp_module_with_head(xyz1, xyz2, p1, p2, [128, 128], 128, 2, False, None, scope='fa',
                                                            head_scope='h1', out_scope='h2').clone()
         finally:
-            U.SA_PRECISION = "fp32"
+            U.SA_PRECISION, U.HOIST_FEATURES = "fp32", True
     assert len(st.__dict__.get("_fp_head_cache", {})) == 1, "fused kernel not taken"
     assert torch.equal(got["persistent"], got["launch"])
     assert got["persistent"].abs().max() > 0

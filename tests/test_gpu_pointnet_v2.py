@@ -241,6 +241,23 @@ def test_fp_head_chain(device, cb):
         outs[mode] = y.cpu().numpy()
     assert len(st.__dict__.get("_fp_head_cache", {})) == 2, "fused kernels not taken"
     close(outs["fused"], outs["layers"], 1e-4)
+    if cb <= 8:
+        # the default took the form that interpolates first-layer products; the form that interpolates the features:
+        assert all("pre" in v for v in st.__dict__["_fp_head_cache"].values())
+        for precision in ("fp32", "bf16"):
+            U.HOIST_FEATURES, U.SA_PRECISION = False, precision
+            try:
+                with variables.use_store(st):
+                    y = U.pointnet_fp_module_with_head(dev(xyz1, device), dev(xyz2, device),
+                                                       None if p1 is None else dev(p1, device), dev(p2, device),
+                                                       [128, 128], 128, 2, False, None, scope='fa', head_scope='h1',
+                                                       out_scope='h2')
+            finally:
+                U.HOIST_FEATURES, U.SA_PRECISION = True, "fp32"
+            if precision == "fp32":
+                close(outs["fused"], y.cpu().numpy(), 1e-5)
+            else:
+                close(y.cpu().numpy(), outs["layers"], 4e-2)
     got, want = outs["bf16"].astype(np.float64), outs["layers"].astype(np.float64)
     s = np.sqrt(np.mean(want ** 2))
     err = (np.abs(got - want) / np.maximum(np.abs(want), s)).max()
