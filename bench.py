@@ -155,6 +155,8 @@ def pmc_kernel_prefix(obs_name):
         targs = "%d, %d, %d, %d" % (cf // 32 if cf >= 32 else 0, w1 // 32, w2 // 32, up(w[2], 128) // 32)
         if not bf16 and cf < 32 and w == [32, 32, 64]:
             return "sa_small_kernel"
+        if not bf16 and cf < 32:  # the persistent kernel of the stacks over coordinates, or its per-group twin
+            return ("sa_persist_kernel<%s," % targs[3:], "sa_chain_kernel<%s>" % targs)
         if bf16 and cf < 32:      # the persistent kernel of the stacks over coordinates
             return "sa_first_bf16_kernel<%s," % targs[3:]
         return ("sa_chain_bf16_kernel<%s," if bf16 else "sa_chain_kernel<%s>") % targs
