@@ -988,7 +988,8 @@ struct SaParams {
     int n, m, ns, cf;
     const float *xyz, *new_xyz, *feat;
     const bf16x8 *featp;                // NJF > 0: the features packed by fpn_sa_pack_features_bf16, or NULL (then feat)
-    const float *pre;                   // NJF = 0: (b,n,32 NT1) what wide features contribute to the first layer, or NULL
+    const float *pre;                   // NJF = 0: (b*n, ldp >= 32 NT1) what wide features contribute to the first layer, or NULL
+    int ldp;
     const int *idx;
     const float *w1, *sc1, *sh1;        // NJF = 0 only: (3+cf, 32 NT1) fp32, scale, shift
     const bf16x8 *ws;
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
                 for (int t = 0; t < NT1; ++t)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4 *>(p.pre + (b * p.n + pid[g]) * (long)(32 * NT1) + 32 * t +
+                        const float4 v = *reinterpret_cast<const float4 *>(p.pre + (b * p.n + pid[g]) * (long)p.ldp + 32 * t +
                                                                            8 * q + 4 * h);
                         init[g][t][4 * q + 0] = v.x; init[g][t][4 * q + 1] = v.y;
                         init[g][t][4 * q + 2] = v.z; init[g][t][4 * q + 3] = v.w;
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_fir
                 for (int t = 0; t < NT1; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        pr[g][t][i] = *reinterpret_cast<const float4 *>(p.pre + q * (32 * NT1) + 32 * t + 8 * i + 4 * h);
+                        pr[g][t][i] = *reinterpret_cast<const float4 *>(p.pre + q * p.ldp + 32 * t + 8 * i + 4 * h);
             }
         }
     };
@@ -2042,7 +2043,8 @@ int fpn_sa_chain_bf16_supported(int cf, int c1, int c2, int c3)
 }
 
 static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                         const float *new_xyz, const float *feat, const void *feat_packed, const float *pre, const int *idx,
+                         const float *new_xyz, const float *feat, const void *feat_packed, const float *pre, int ld_pre,
+                         const int *idx,
                          const void *wstream, const float *const *consts, float *out, int ldo, int c3_valid,
                          void *stream)
 {
@@ -2064,6 +2066,7 @@ static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, in
     p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.idx = idx;
     p.featp = static_cast<const bf16x8 *>(feat_packed);
     p.pre = pre;
+    p.ldp = ld_pre;
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     if (njf == 0) {       // consts: w1, scale1, shift1, shift2, shift3
         for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "sa_chain_bf16: constant %d is null", i);
@@ -2095,18 +2098,19 @@ int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c
                       const float *new_xyz, const float *feat, const int *idx, const void *wstream,
                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
 {
-    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, nullptr, idx, wstream, consts, out, ldo,
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, nullptr, 0, idx, wstream, consts, out, ldo,
                          c3_valid, stream);
 }
 
 int fpn_sa_chain_pre_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                          const float *new_xyz, const float *feat, const float *pre, const int *idx, const void *wstream,
-                          const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
+                          const float *new_xyz, const float *feat, const float *pre, int ld_pre, const int *idx,
+                          const void *wstream, const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
 {
     FPN_REQUIRE(cf <= 1, "sa_chain_pre_bf16: at most one direct feature channel beside the first-layer products (cf = %d)", cf);
-    FPN_REQUIRE((pre || b == 0) && (reinterpret_cast<uintptr_t>(pre) & 15) == 0, "sa_chain_pre_bf16: null or misaligned products");
-    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, pre, idx, wstream, consts, out, ldo, c3_valid,
-                         stream);
+    FPN_REQUIRE((pre || b == 0) && (reinterpret_cast<uintptr_t>(pre) & 15) == 0 && ld_pre >= c1 && ld_pre % 4 == 0,
+                "sa_chain_pre_bf16: null or misaligned products, or a row stride (%d) below c1 or no multiple of 4", ld_pre);
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, pre, ld_pre, idx, wstream, consts, out, ldo,
+                         c3_valid, stream);
 }
 
 int fpn_sa_chain_bf16p(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
@@ -2114,7 +2118,7 @@ int fpn_sa_chain_bf16p(int b, int n, int m, int ns, int cf, int c1, int c2, int 
                        const float *const *consts, float *out, int ldo, int c3_valid, void *stream)
 {
     FPN_REQUIRE(cf >= 32, "sa_chain_bf16p: packed features exist for cf >= 32 only (cf = %d)", cf);
-    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, nullptr, feat_packed, nullptr, idx, wstream, consts, out,
+    return sa_chain_bf16(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, nullptr, feat_packed, nullptr, 0, idx, wstream, consts, out,
                          ldo, c3_valid, stream);
 }
 

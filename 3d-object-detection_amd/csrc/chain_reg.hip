@@ -855,7 +855,8 @@ struct SaChainParams {
     const float *xyz;     // (b,n,3)
     const float *new_xyz; // (b,m,3)
     const float *feat;    // (b,n,cf) or NULL
-    const float *pre;     // NJF = 0: (b,n,32 NT1) what wide point features contribute to the first layer, or NULL
+    const float *pre;     // NJF = 0: (b*n, ldp >= 32 NT1) what wide point features contribute to the first layer, or NULL
+    int ldp;
     const int *idx;       // (b,m,ns)
     const float *w1; const float *sc1, *sh1;     // NJF > 0: chunked ((NJF+1)*32, 32 NT1); NJF = 0: plain (3+cf, 32 NT1)
     const float4 *w2; const float *sc2, *sh2;
@@ -935,7 +936,7 @@ __global__ __launch_bounds__(64 * kRegWaves, NJF == 0 ? 2 : 1) void sa_chain_ker
             x[s] = v;
         }
         FPN_STAMP(1);
-        first.apply(a1, x, h, p.pre ? p.pre + (b * p.n + pid) * (long)(32 * NT1) : nullptr);
+        first.apply(a1, x, h, p.pre ? p.pre + (b * p.n + pid) * (long)p.ldp : nullptr);
         FPN_STAMP(2);
         layer_t<NT1, NT2, 0>(a2, a1, p.w2, p.sc2, p.sh2, ring, p.w3, p.w3 + (size_t)NT2 * 256, lane, h);
         FPN_STAMP(3);
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(64 * kRegWaves, W3LDS ? 2 : 1) void sa_persist_kern
             for (int t = 0; t < NT1; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    pr[t][i] = *reinterpret_cast<const float4 *>(p.pre + q * (32 * NT1) + 32 * t + 8 * i + 4 * h);
+                    pr[t][i] = *reinterpret_cast<const float4 *>(p.pre + q * p.ldp + 32 * t + 8 * i + 4 * h);
         }
     };
     load_x(c0);
@@ -1567,12 +1568,13 @@ int fpn_sa_chain_supported(int cf, int c1, int c2, int c3)
 }
 
 static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                        const float *new_xyz, const float *feat, const float *pre, const int *idx,
+                        const float *new_xyz, const float *feat, const float *pre, int ld_pre, const int *idx,
                         const float *const *layers, float *out, int ldo, int c3_valid, void *stream)
 {
     FPN_REQUIRE(b >= 0 && n >= 1 && m >= 1 && ns >= 1 && cf >= 0, "sa_chain: bad size");
-    FPN_REQUIRE(!pre || (cf < 32 && (reinterpret_cast<uintptr_t>(pre) & 15) == 0),
-                "sa_chain: first-layer products go with fewer than 32 direct feature channels and a 16-byte aligned array");
+    FPN_REQUIRE(!pre || (cf < 32 && (reinterpret_cast<uintptr_t>(pre) & 15) == 0 && ld_pre >= c1 && ld_pre % 4 == 0),
+                "sa_chain: first-layer products go with fewer than 32 direct feature channels, a 16-byte aligned array and "
+                "a row stride (%d) of at least c1 floats, a multiple of 4", ld_pre);
     FPN_REQUIRE(ns % 32 == 0, "sa_chain: samples per ball (%d) must be a multiple of 32", ns);
     // the last layer works on pairs of 32-channel tiles: a valid width ends on a pair
     FPN_REQUIRE(c3_valid >= 64 && c3_valid % 64 == 0 && c3_valid <= c3 && ldo >= c3_valid,
@@ -1584,7 +1586,7 @@ static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int
     for (int i = 0; i < 9; ++i) FPN_REQUIRE(layers[i], "sa_chain: layer parameter %d is null", i);
     SaChainParams p{};
     p.rows = (long)b * m * ns; p.n = n; p.m = m; p.ns = ns; p.cf = cf;
-    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.pre = pre; p.idx = idx;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.feat = feat; p.pre = pre; p.ldp = ld_pre; p.idx = idx;
     p.w1 = layers[0]; p.sc1 = layers[1]; p.sh1 = layers[2];
     p.w2 = reinterpret_cast<const float4 *>(layers[3]); p.sc2 = layers[4]; p.sh2 = layers[5];
     p.w3 = reinterpret_cast<const float4 *>(layers[6]); p.sc3 = layers[7]; p.sh3 = layers[8];
@@ -1621,15 +1623,15 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
                      const float *new_xyz, const float *feat, const int *idx, const float *const *layers,
                      float *out, int ldo, int c3_valid, void *stream)
 {
-    return sa_chain_f32(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, idx, layers, out, ldo, c3_valid, stream);
+    return sa_chain_f32(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, nullptr, 0, idx, layers, out, ldo, c3_valid, stream);
 }
 
 int fpn_sa_chain_pre_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                         const float *new_xyz, const float *feat, const float *pre, const int *idx,
+                         const float *new_xyz, const float *feat, const float *pre, int ld_pre, const int *idx,
                          const float *const *layers, float *out, int ldo, int c3_valid, void *stream)
 {
     FPN_REQUIRE(pre || b == 0, "sa_chain_pre: null pointer");
-    return sa_chain_f32(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, pre, idx, layers, out, ldo, c3_valid, stream);
+    return sa_chain_f32(b, n, m, ns, cf, c1, c2, c3, xyz, new_xyz, feat, pre, ld_pre, idx, layers, out, ldo, c3_valid, stream);
 }
 
 int fpn_fp_head_chain_f32(long rows, int ca, int cb, const float *xa, const float *xb,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class FpnError(RuntimeError):
@@ -57,7 +57,7 @@ SIGNATURES = {
     "fpn_sa_chain_supported": [_i, _i, _i, _i],
     "fpn_sa_chain_bf16_supported": [_i, _i, _i, _i],
     "fpn_sa_chain_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "fpn_sa_chain_pre_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "fpn_sa_chain_pre_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
@@ -69,7 +69,7 @@ SIGNATURES = {
     "fpn_v1_seg_tail_bf16": [_l, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp],
     "fpn_v1_obj_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _i, _vp],
     "fpn_sa_chain_bf16": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "fpn_sa_chain_pre_bf16": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "fpn_sa_chain_pre_bf16": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_sa_chain_bf16p": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_sa_pack_features_bf16": [_l, _i, _vp, _vp, _vp],
     "fpn_fp_head_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp],

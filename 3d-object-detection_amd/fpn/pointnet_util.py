@@ -245,11 +245,14 @@ def _pack_features(points):
     return packed
 
 
-def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first, zeroed=False, packed=None):
+def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first, zeroed=False, shared=None):
     """Grouping + 3-layer MLP + max over the samples in one kernel (fpn_sa_chain_f32).
     out2d (b*m, widths[-1]) may be a column slice of a wider buffer; the kernel merges its
     maxima into it, so it must start at zero (`zeroed`: the caller has cleared it).  Returns
-    False when the shape has no fused kernel (the caller then runs the per-layer path)."""
+    False when the shape has no fused kernel (the caller then runs the per-layer path).
+    `shared`: a dict the scales of a multi-scale module pass along - the packed bf16 feature
+    table ("packed", made by the first scale that gathers features) and the first-layer products
+    of all scales ("pre": {first-layer scope: (matrix, column offset)}, see _msg_products)."""
     b, n, _ = xyz.shape
     _, m, ns = idx.shape
     cf = 0 if points is None else points.shape[2]
@@ -274,25 +277,38 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
                                                            ",pre=%d" % cf if hoisted else ""),
                         b * m * ns, 0, 0, macs=b * m * ns * macs)
     with torch.cuda.device(xyz.device):
+        pre = None
+        if hoisted:
+            made = (shared or {}).get("pre", {}).get(names[0])
+            if made is not None:        # a column block of the module's one matrix of products
+                pre = made[0][:, made[1]:made[1] + pad[0]]
+            elif "stream" in plan:
+                pre = ops.shared_mlp(points.reshape(b * n, cf), plan["w1f"], plan["s1"], None, relu=False,
+                                     wt_bf16=plan["w1f_bf16"])
+            else:
+                # (:184 before :187-190 in the reference's order: per gathered row; here per point, then gathered)
+                pre = ops.shared_mlp(points.reshape(b * n, cf), plan["w1f"], None, None, relu=False)
         if "stream" in plan and hoisted:
-            pre = ops.shared_mlp(points.reshape(b * n, cf), plan["w1f"], plan["s1"], None, relu=False, wt_bf16=plan["w1f_bf16"])
             _lib.check(_lib.load().fpn_sa_chain_pre_bf16(b, n, m, ns, 0, pad[0], pad[1], pad[2], _lib.ptr(xyz),
-                                                         _lib.ptr(new_xyz), None, _lib.ptr(pre), _lib.ptr(idx),
+                                                         _lib.ptr(new_xyz), None, _lib.ptr(pre), pre.stride(0), _lib.ptr(idx),
                                                          _lib.ptr(plan["stream"]), plan["table"], _lib.ptr(out2d), ldo,
                                                          int(widths[2]), _lib.stream_of(xyz)))
         elif "stream" in plan:
-            if packed is None and PACK_FEATURES and cf >= 32 and cf % 32 == 0:
-                packed = _pack_features(points)
+            packed = None
+            if PACK_FEATURES and cf >= 32 and cf % 32 == 0:
+                holder = shared if shared is not None else {}
+                if holder.get("packed") is None:
+                    holder["packed"] = _pack_features(points)
+                packed = holder["packed"]
             entry = _lib.load().fpn_sa_chain_bf16 if packed is None else _lib.load().fpn_sa_chain_bf16p
             _lib.check(entry(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz), _lib.ptr(new_xyz),
                              _lib.ptr(points if packed is None else packed), _lib.ptr(idx), _lib.ptr(plan["stream"]),
                              plan["table"], _lib.ptr(out2d), ldo, int(widths[2]), _lib.stream_of(xyz)))
-        elif "w1f" in plan:
-            # (:184 before :187-190 in the reference's order: per gathered row; here per point, then gathered)
-            pre = ops.shared_mlp(points.reshape(b * n, cf), plan["w1f"], None, None, relu=False)
+        elif hoisted:
             _lib.check(_lib.load().fpn_sa_chain_pre_f32(b, n, m, ns, 0, pad[0], pad[1], pad[2], _lib.ptr(xyz),
-                                                        _lib.ptr(new_xyz), None, _lib.ptr(pre), _lib.ptr(idx), plan["table"],
-                                                        _lib.ptr(out2d), ldo, int(widths[2]), _lib.stream_of(xyz)))
+                                                        _lib.ptr(new_xyz), None, _lib.ptr(pre), pre.stride(0), _lib.ptr(idx),
+                                                        plan["table"], _lib.ptr(out2d), ldo, int(widths[2]),
+                                                        _lib.stream_of(xyz)))
         else:
             _lib.check(_lib.load().fpn_sa_chain_f32(b, n, m, ns, cf, pad[0], pad[1], pad[2], _lib.ptr(xyz),
                                                     _lib.ptr(new_xyz), _lib.ptr(points), _lib.ptr(idx), plan["table"],
@@ -417,6 +433,38 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         return new_xyz, pooled.reshape(b, m, pooled.shape[-1]), idx
 
 
+def _msg_products(points, names_list, mlp_list, bn):
+    """The first-layer products (HOIST_FEATURES) of every scale of a multi-scale module in ONE
+    launch over the points: the scales' feature rows of W1 side by side as the columns of one
+    matrix.  Returns {first-layer scope: (products (b*n, total), column offset)} for the scales
+    whose fused kernel takes products; {} when there are fewer than two."""
+    b, n, cf = points.shape
+    store = variables.get_default_store()
+    plans = []
+    for names, widths in zip(names_list, mlp_list):
+        plan = _sa_chain_plan(store, names, cf, widths, bn, False) if len(widths) == 3 and widths[2] % 64 == 0 else None
+        if plan is not None and "w1f" in plan:
+            plans.append((names[0], plan))
+    if len(plans) < 2:
+        return {}
+    cache = store.__dict__.setdefault("_msg_products_cache", {})
+    key = (tuple(nm for nm, _ in plans), SA_PRECISION)
+    hit = cache.get(key)
+    if hit is None or hit["version"] != store.version:
+        w = torch.cat([pl["w1f"] for _, pl in plans], dim=1).contiguous()
+        bf16 = "stream" in plans[0][1]
+        hit = {"version": store.version, "w": w,
+               "scale": torch.cat([pl["s1"] for _, pl in plans]).contiguous() if bf16 else None,
+               "wt": ops.pack_mlp_bf16(w) if bf16 else None}
+        cache[key] = hit
+    pre = ops.shared_mlp(points.reshape(b * n, cf), hit["w"], hit["scale"], None, relu=False, wt_bf16=hit["wt"])
+    made, off = {}, 0
+    for nm, pl in plans:
+        made[nm] = (pre, off)
+        off += pl["w1f"].shape[1]
+    return made
+
+
 def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training, bn_decay,
                            scope, bn=True, use_xyz=True, use_nchw=False):
     """Multi-scale-grouping set abstraction.  Reference: pointnet_util.py:155-195.
@@ -429,10 +477,11 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         width = sum(w[-1] for w in mlp_list)
         # (one clear for all scales: the fused kernels merge their maxima into it)
         out = torch.zeros((b * m, width), dtype=torch.float32, device=xyz.device)
-        packed = None
-        if SA_PRECISION == "bf16" and PACK_FEATURES and FUSE_SA and points is not None and use_xyz \
-                and points.shape[2] >= 32 and points.shape[2] % 32 == 0:
-            packed = _pack_features(points)       # one table for all scales
+        shared = {}         # what the scales have in common: the packed feature table, the first-layer products
+        if FUSE_SA and points is not None and use_xyz:
+            points = points.contiguous()
+            shared["pre"] = _msg_products(points, [[variables.scoped('conv%d_%d' % (i, j)) for j in range(3)]
+                                                   for i in range(len(mlp_list))], mlp_list, bn)
         col = 0
         # all radii in one sweep over the points (the same index tables as one query per radius, :178)
         balls = query_ball_point_multi(radius_list, nsample_list, xyz, new_xyz, counts=False)
@@ -442,7 +491,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             if (points is None or use_xyz) and FUSE_SA and \
                     _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx, mlp_list[i],
                               'conv%d_' % i + '%d', bn, out[:, col:col + w_i], xyz_first=False,
-                              zeroed=True, packed=packed):                                                      # :176-192 in one kernel
+                              zeroed=True, shared=shared):                                                      # :176-192 in one kernel
                 col += w_i
                 continue
             if points is not None and use_xyz:

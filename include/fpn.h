@@ -410,15 +410,17 @@ int fpn_sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3
  * is linear before its batch norm and ReLU and a point is gathered into many balls
  * (models/pointnet_util.py:43-49, :177-184 group and concatenate, :187-190 multiply), so the
  * product of a point's features with their rows of the first layer is the same in every
- * ball: the caller computes it once per point - pre (b*n, c1) fp32 = features . W1[feature
- * rows], no scale, no shift, c1 the padded width, 16-byte aligned - and the kernel gathers
+ * ball: the caller computes it once per point - pre (b*n, ld_pre >= c1) fp32 = features .
+ * W1[feature rows], no scale, no shift, c1 the padded width, 16-byte aligned, ld_pre % 4 == 0
+ * (the products of all scales of a multi-scale module can be the column blocks of one
+ * matrix, made by one launch) - and the kernel gathers
  * pre[idx] as the first layer's starting value, adds the relative coordinates' (and up to 5
  * direct feature channels') part, then scale, shift and ReLU as before.  cf, feat, layers:
  * as for cf < 32 above (w1 holds the rows of the coordinates and direct channels only).
  * Besides the cf < 32 shapes of fpn_sa_chain_supported, widths 128,128,256. */
 int fpn_sa_chain_pre_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3,
                          const float *xyz, const float *new_xyz, const float *feat, const float *pre,
-                         const int *idx, const float *const *layers, float *out, int ldo,
+                         int ld_pre, const int *idx, const float *const *layers, float *out, int ldo,
                          int c3_valid, void *stream);
 
 /*
@@ -514,14 +516,14 @@ int fpn_sa_chain_bf16_supported(int cf, int c1, int c2, int c3);
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                       const float *new_xyz, const float *feat, const int *idx, const void *wstream,
                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream);
-/* fpn_sa_chain_pre_f32's form on bf16 operands: pre (b*n, c1) fp32 = features . (W1[feature
+/* fpn_sa_chain_pre_f32's form on bf16 operands: pre (b*n, ld_pre) fp32 = features . (W1[feature
  * rows] . diag(scale1)) - scaled like the stream's weights, no shift - gathered as the first
  * layer's starting value; cf <= 1 direct channels; consts and stream as for cf < 32; widths as
  * there, and 128,128,256. */
 int fpn_sa_chain_pre_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
-                          const float *new_xyz, const float *feat, const float *pre, const int *idx,
-                          const void *wstream, const float *const *consts, float *out, int ldo,
-                          int c3_valid, void *stream);
+                          const float *new_xyz, const float *feat, const float *pre, int ld_pre,
+                          const int *idx, const void *wstream, const float *const *consts, float *out,
+                          int ldo, int c3_valid, void *stream);
 /* The same for cf >= 32 with the point features converted once instead of once per gathered
  * row: fpn_sa_pack_features_bf16 turns feat (points, cf) fp32 (cf % 32 == 0, 16-byte
  * aligned) into `packed` (points * cf bf16, an internal operand order, meaningful only to
