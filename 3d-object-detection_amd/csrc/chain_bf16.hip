@@ -68,6 +68,12 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+// LDS executes one wave's instructions in issue order: what is needed between the ds_max updates of a row and
+// the wave's own reads of it (and between those reads and the next updates) is only that the COMPILER keeps
+// the order.  (A fence, even at wavefront scope, also waits for the wave's outstanding memory reads - the
+// next round's inputs.)
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 struct Act {            // 32 channels of 32 points as two operand fragments
     bf16x8 m[2];
 };
@@ -381,18 +387,24 @@ __device__ __forceinline__ void unit_mfma_from(floatx16 (&acc)[2][NP], const WUn
 // write instead, all placed behind the unit's FIRST MFMA: the barrier that may end the
 // unit waits for every LDS operation of the wave, so they get the rest of the unit's MFMAs
 // to complete in.
-template <int MODE, int NMFMA, int NVMEM, int NVALU>
+template <int MODE, int NMFMA, int NVMEM, int NVALU, int NHOOK = 0>
 __device__ __forceinline__ void sched_unit()
 {
     constexpr bool COOP = MODE == 1;
-    if constexpr (MODE == 2) {      // LdsFeed: the weights and the layer constants are all LDS reads
-        constexpr int PER = (NVMEM + NMFMA - 1) / NMFMA;
-#pragma unroll
-        for (int m = 0; m < NMFMA; ++m) {
+    if constexpr (MODE == 2) {      // LdsFeed: the weights and the layer constants are all LDS reads;
+        // NHOOK: memory reads a caller's hook issued in this unit (the next round's inputs), one behind each MFMA
+        constexpr int PER = (NVMEM + NMFMA - 1) / NMFMA, HPER = (NHOOK + NMFMA - 1) / NMFMA;
+        static_for<0, NMFMA>([&](auto M) {
+            constexpr int m = decltype(M)::value;
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (m * PER < NVMEM) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
-        }
+            if constexpr (m * PER < NVMEM) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+            if constexpr (m * HPER < NHOOK) {       // (with the address arithmetic of the reads)
+                __builtin_amdgcn_sched_group_barrier(0x020, HPER, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NVALU + 4 * HPER, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+            }
+        });
         __builtin_amdgcn_sched_barrier(0);
         return;
     }
@@ -457,9 +469,17 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
 // LdsFeed: the shifts lie in LDS, a pair's are read during the last unit of the pair before;
 // with RingFeed the same arithmetic, the shifts then come from memory).  csh: the
 // shifts of the layer's FIRST pair, read by the caller early enough.
-template <int NP, int NJ, int NT, int R0, class Out, class Feed>
+struct NoHook {
+    template <class I>
+    __device__ __forceinline__ void operator()(I) const {}
+};
+
+// hook(integral_constant<unit>): called once in every unit, for work of the caller's that should issue between
+// this layer's MFMAs (NHOOK memory reads per unit at most)
+template <int NP, int NJ, int NT, int R0, int NHOOK = 0, class Out, class Feed, class Hook = NoHook>
 __device__ __forceinline__ void layer_t_from(Out (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
-                                             const float *__restrict__ sh, Feed &feed, int h, TileConst (&csh)[2])
+                                             const float *__restrict__ sh, Feed &feed, int h, TileConst (&csh)[2],
+                                             Hook &&hook = Hook())
 {
     static_assert(NJ >= 2 && Feed::kMode != 1, "unsupported layer shape");
     constexpr int NPAIR = (NT + 1) / 2;
@@ -482,8 +502,9 @@ __device__ __forceinline__ void layer_t_from(Out (&out)[NP][NT], const Act (&in)
             load_const(csh[0], sh, 32 * (2 * tp + 2) + 4 * h);
             if constexpr (nnext == 2) load_const(csh[1], sh, 32 * (2 * tp + 3) + 4 * h);
         }
+        hook(I);
         sched_unit<Feed::kMode, 2 * ntile * NP, more ? 4 + 4 * nnext : 4,
-                   (tp > 0 && j < 2) ? (32 * NP + 2 * ntile * NP - 1) / (2 * ntile * NP) : 1>();
+                   (tp > 0 && j < 2) ? (32 * NP + 2 * ntile * NP - 1) / (2 * ntile * NP) : 1, NHOOK>();
     });
     constexpr int last = (NPAIR - 1) & 1;
 #pragma unroll
@@ -1248,10 +1269,42 @@ __global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_fir
                         init[g][t][4 * i + 2] = pr[g][t][i].z; init[g][t][4 * i + 3] = pr[g][t][i].w;
                     }
         }
+        // The next round's inputs (and the round after's indices, last: the addresses above come from the ones
+        // held now) are requested between the second layer's MFMAs, a few per unit: issued in one burst at the top
+        // of the round, 13 to 45 gathers of 64 different lines each kept the wave from issuing MFMAs for 0.7-3 k
+        // of a round's 3-10 k cycles.
+        const unsigned cn = min(c + 1, c1 - 1), cnn = min(c + 2, c1 - 1);
+        const unsigned balln = cn / cpb, bn = balln / p.m;
+        size_t qn[NP];
+#pragma unroll
+        for (int g = 0; g < NP; ++g) qn[g] = (size_t)bn * p.n + pid[g];
+        constexpr int NPRE = PRE ? NP * NT1 * 4 : 0, NX = NP * KP, NL = NPRE + NX + 3 + NP;
+        constexpr int PER = (NL + U2 - 1) / U2;
+        auto issue = [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j < NPRE) {
+                constexpr int g = j / (NT1 * 4), t = (j / 4) % NT1, i = j % 4;
+                pr[PRE ? g : 0][t][i] = *reinterpret_cast<const float4 *>(p.pre + qn[g] * p.ldp + 32 * t + 8 * i + 4 * h);
+            } else if constexpr (j < NPRE + NX) {
+                constexpr int g = (j - NPRE) / KP, k = (j - NPRE) % KP;
+                float v = 0.f;
+                if (k < 3) v = p.xyz[qn[g] * 3 + k];
+                else if (k < 3 + p.cf) v = p.feat[qn[g] * p.cf + k - 3];
+                xr[g][k] = v;
+            } else if constexpr (j < NPRE + NX + 3) {
+                constexpr int k = j - NPRE - NX;
+                cr[k] = p.new_xyz[(size_t)balln * 3 + k];
+            } else {
+                constexpr int g = j - NPRE - NX - 3;
+                pid[g] = p.idx[(size_t)cnn * (32 * NP) + 32 * g + pt];
+            }
+        };
+        auto hook = [&](auto I) {
 #ifndef FPN_SAP_NOGATHER      // (timing-only builds, wrong results: FPN_SAP_NO*)
-        load_x(min(c + 1, c1 - 1));
-        load_idx(min(c + 2, c1 - 1));
+            constexpr int S = decltype(I)::value;
+            static_for<S * PER, ((S + 1) * PER < NL ? (S + 1) * PER : NL)>(issue);
 #endif
+        };
         TileConst c2[2];        // the second layer's first shifts: wanted after the first layer
         load_const(c2[0], lsh2, 4 * h);
         load_const(c2[1], lsh2, 32 + 4 * h);
@@ -1271,7 +1324,7 @@ __global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_fir
                 for (int f = 0; f < 2; ++f) asm volatile("" : "=v"(a1[g][t].m[f]) : "v"(x[g][0]));
 #endif
         FPN_PSTAMP(2);
-        layer_t_from<NP, NT1, NT2, 0>(a2, a1, ws, lsh2, feed, h, c2);
+        layer_t_from<NP, NT1, NT2, 0, PER>(a2, a1, ws, lsh2, feed, h, c2, hook);
         FPN_PSTAMP(3);
         layer_max<NP, NT2, NT3, U2 % kRing>(a2, ws + U2 * kUnitVecs, lsh3, lmax, feed, lane, p.c3);
         FPN_PSTAMP(4);
@@ -1281,7 +1334,7 @@ __global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_fir
 #else
         if (++in_ball == cpb) {             // the ball is complete: its row leaves, the LDS row starts again from zero
 #endif
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            lds_order();
             float *out = p.out + (size_t)ball * p.ldo;
 #pragma unroll
             for (int ch = lane; ch < C; ch += 64) {
@@ -1289,7 +1342,7 @@ __global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_fir
                 lmax[ch] = 0;
                 if (ch < p.c3) out[ch] = __int_as_float(v);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            lds_order();
             in_ball = 0;
             ++ball;
         }

@@ -72,6 +72,12 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+// LDS executes one wave's instructions in issue order: what is needed between the ds_max updates of a row and
+// the wave's own reads of it (and between those reads and the next updates) is only that the COMPILER keeps
+// the order.  (A fence, even at wavefront scope, also waits for the wave's outstanding memory reads - the
+// next round's inputs.)
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 struct WChunk {          // the 16 weights of a lane for the 16 MFMA steps of one
     float4 q[4];         // (output tile, input tile) pair: step r = 4q + i
 };
@@ -1088,7 +1094,7 @@ __global__ __launch_bounds__(64 * kRegWaves, W3LDS ? 2 : 1) void sa_persist_kern
         layer_max<NT2, NT3, P2>(a2, lw3, lsc3, lsh3, lmax, ring, lane, h, p.c3);
 
         if (++in_ball == rpb) {                 // the ball is complete: its row leaves, the LDS row starts again from zero
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            lds_order();
             float *out = p.out + (size_t)ball * p.ldo;
 #pragma unroll
             for (int ch = lane; ch < C; ch += 64) {
@@ -1096,7 +1102,7 @@ __global__ __launch_bounds__(64 * kRegWaves, W3LDS ? 2 : 1) void sa_persist_kern
                 lmax[ch] = 0;
                 if (ch < p.c3) out[ch] = __int_as_float(v);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            lds_order();
             in_ball = 0;
             ++ball;
         }
