@@ -43,6 +43,34 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     # empty problems are accepted without touching the device
     assert lib.fpn_gather_point(0, 8, 4, None, None, None, None) == 0
     assert lib.fpn_group_point(2, 8, 3, 0, 4, None, None, None, None) == 0
+    # the multi-radius query: 1..4 radii, each positive
+    P = ctypes.c_void_p(16)
+    assert lib.fpn_query_ball_point_multi(1, 8, 4, 5, P, P, P, P, P, P, None) == -1
+    assert lib.fpn_query_ball_point_multi(1, 8, 4, 0, P, P, P, P, P, P, None) == -1
+    # which padded set-abstraction shapes have a fused kernel
+    assert lib.fpn_sa_chain_supported(1, 32, 32, 64) == 1 and lib.fpn_sa_chain_bf16_supported(1, 32, 32, 64) == 0
+    assert lib.fpn_sa_chain_supported(0, 128, 128, 256) == 1 and lib.fpn_sa_chain_supported(0, 128, 128, 128) == 0
+    assert lib.fpn_sa_chain_bf16_supported(640, 128, 256, 1024) == 1 and lib.fpn_sa_chain_supported(640, 128, 256, 1024) == 0
+    assert lib.fpn_sa_chain_bf16_supported(1, 64, 96, 128) == 1 and lib.fpn_sa_chain_bf16_supported(320, 64, 96, 128) == 0
+    # first-layer products: aligned, a row stride of at least c1 floats, no wide direct features beside them
+    assert lib.fpn_sa_chain_pre_f32(1, 8, 2, 32, 0, 64, 64, 128, P, P, None, ctypes.c_void_p(20), 64, P, P, P, 128, 128,
+                                    None) == -1
+    assert lib.fpn_sa_chain_pre_f32(1, 8, 2, 32, 0, 64, 64, 128, P, P, None, P, 32, P, P, P, 128, 128, None) == -1
+    assert b"row stride" in lib.fpn_last_error_string()
+    assert lib.fpn_sa_chain_pre_f32(1, 8, 2, 32, 64, 64, 64, 128, P, P, P, P, 64, P, P, P, 128, 128, None) == -1
+    table = (ctypes.c_void_p * 9)(*([16] * 9))         # (read by the library, not dereferenced before the refusal)
+    assert lib.fpn_sa_chain_pre_f32(1, 8, 2, 32, 0, 32, 32, 64, P, P, None, P, 32, P, table, P, 64, 64, None) == -1
+    assert b"32-32-64" in lib.fpn_last_error_string()
+    assert lib.fpn_sa_chain_pre_bf16(1, 8, 2, 32, 2, 64, 64, 128, P, P, P, P, 64, P, P, P, P, 128, 128, None) == -1
+    assert lib.fpn_sa_chain_bf16(1, 8, 2, 32, 0, 128, 128, 256, P, P, None, P, P, P, P, 256, 256, None) == -3
+    assert b"products only" in lib.fpn_last_error_string()
+    assert lib.fpn_sa_chain_pre_f32(0, 8, 2, 32, 0, 64, 64, 128, None, None, None, None, 64, None, None, None, 128, 128,
+                                    None) == 0
+    # the heads on interpolated products: at most 8 own channels, rows in groups of 32
+    assert lib.fpn_fp_head_chain_pre_f32(64, 9, P, P, P, P, None) == -1
+    assert lib.fpn_fp_head_chain_pre_f32(48, 4, P, P, P, P, None) == -1
+    assert lib.fpn_fp_head_chain_pre_bf16(64, 9, P, P, P, P, P, None) == -1
+    assert lib.fpn_fp_head_chain_pre_bf16(0, 4, None, None, None, None, None, None) == 0
 
 
 def test_ball_threshold_equals_sqrt_test():
