@@ -531,6 +531,26 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             if len(mlp) > 1:
                 y = _mlp_stack(y, mlp[1:], 'conv_%d', bn, first=1)
             return y.reshape(b, n, y.shape[-1])
+        if FUSE_SA and HOIST_FEATURES and points1 is not None and len(mlp) >= 1 and mlp[0] <= points2.shape[2]:
+            # interpolation (:210-215) and the first convolution before its batch norm (:222-226) are linear: the
+            # KNOWN points go through the interpolated features' rows of W1 once, the products are interpolated and
+            # enter the first layer over the dense points' own features as a per-row bias - the concatenation
+            # (:218) is not made
+            b, n, c1 = points1.shape
+            m, c2 = points2.shape[1], points2.shape[2]
+            store = variables.get_default_store()
+            name0 = variables.scoped('conv_0')
+            w, scale, shift = _layer_params(store, name0, c2 + c1, mlp[0], bn)
+            bf16 = SA_PRECISION == "bf16" and b * n >= BF16_LAYER_MIN_ROWS
+            known = ops.shared_mlp(points2.contiguous().reshape(b * m, c2), w[:c2], None, None, relu=False,
+                                   wt_bf16=_packed_bf16(store, name0 + "#known", w[:c2]) if bf16 else None)
+            part = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), known.reshape(b, m, mlp[0]))
+            y = ops.shared_mlp(points1.contiguous().reshape(b * n, c1), w[c2:], scale, shift, relu=True,
+                               group_bias=part.reshape(b * n, mlp[0]), rows_per_group=1,
+                               wt_bf16=_packed_bf16(store, name0 + "#own", w[c2:]) if bf16 else None)
+            if len(mlp) > 1:
+                y = _mlp_stack(y, mlp[1:], 'conv_%d', bn, first=1)
+            return y.reshape(b, n, y.shape[-1])
         interpolated = three_nn_interpolate(xyz1.contiguous(), xyz2.contiguous(), points2.contiguous())  # :210-215
         new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated  # :218
         b, n, c = new_points1.shape
