@@ -286,6 +286,7 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
     float *red = Xs[0];  // (BM/32, BN) tile maxima; the K loop ended on a barrier
     const bool pooled = p.pool_rows > 0;
     const bool gb_tile_uniform = p.group_bias && (p.rows_per_group % 32 == 0);
+    const bool gb_per_row = p.rows_per_group == 1;       // (a bias row per row: no 64-bit division per element)
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = col0 + (wn * TN + b) * 32 + l31;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
                 float v = acc[a][b][r];
                 if (p.group_bias) {
                     if (gb_tile_uniform) v += gbu;
-                    else if (colok && row < p.rows) v += p.group_bias[(row / p.rows_per_group) * p.cout + col];
+                    else if (colok && row < p.rows) v += p.group_bias[(gb_per_row ? row : row / p.rows_per_group) * p.cout + col];
                 }
                 v = v * sc + sh;
                 if (p.relu) v = fmaxf(v, 0.f);
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_kernel(const MlpParams
 // of both images are 72 bf16 = 144 bytes apart: 16 consecutive rows then start in 16
 // different groups of four banks.  A workgroup owns 128 rows x 128 columns (2 x 2 waves,
 // 2 x 2 tiles each) and walks K 64 at a time through double-buffered images, one barrier
-// per step.  Epilogue as shared_mlp_kernel (group bias, scale, shift, ReLU, max over
+// per step.  (Requesting tile t + 2 into a second register set while tile t multiplies was
+// measured and made the kernel a third slower - 175 -> 259 us on 131 k rows x 320 -> 320.)  Epilogue as shared_mlp_kernel (group bias, scale, shift, ReLU, max over
 // groups of rows), all in fp32.
 // ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -379,8 +381,13 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_kernel(const MlpP
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
     const int ncb = (p.cout + BN - 1) / BN;
-    const long row0 = (long)(blockIdx.x / ncb) * BM;
-    const int col0 = (int)(blockIdx.x % ncb) * BN;
+    // The column tiles of one block of rows read the same rows of x: consecutive workgroup ids go round the eight
+    // XCDs, each with its own L2, so id i takes logical block (i % 8) * (grid / 8) + i / 8 - the tiles of a row
+    // block then share an XCD (measured on 131 k rows x 320 -> 320: 180 -> 169 us).
+    const unsigned g = gridDim.x, bi = blockIdx.x;
+    const unsigned blk = (ncb > 1 && g % 8 == 0) ? (bi % 8) * (g / 8) + bi / 8 : bi;
+    const long row0 = (long)(blk / ncb) * BM;
+    const int col0 = (int)(blk % ncb) * BN;
     const __bf16 *wt = reinterpret_cast<const __bf16 *>(p.w);
     const int ldw = (p.cin + kHK - 1) / kHK * kHK;
     const int ktiles = ldw / kHK;
@@ -471,6 +478,7 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_kernel(const MlpP
     float *red = reinterpret_cast<float *>(Xs[0]);  // (BM/32, BN) tile maxima; the K loop ended on a barrier
     const bool pooled = p.pool_rows > 0;
     const bool gb_tile_uniform = p.group_bias && (p.rows_per_group % 32 == 0);
+    const bool gb_per_row = p.rows_per_group == 1;       // (a bias row per row: no 64-bit division per element)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int col = col0 + (wn * 2 + b) * 32 + l31;
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_kernel(const MlpP
                 float v = acc[a][b][r];
                 if (p.group_bias) {
                     if (gb_tile_uniform) v += gbu;
-                    else if (colok && row < p.rows) v += p.group_bias[(row / p.rows_per_group) * p.cout + col];
+                    else if (colok && row < p.rows) v += p.group_bias[(gb_per_row ? row : row / p.rows_per_group) * p.cout + col];
                 }
                 v = v * sc + sh;
                 if (p.relu) v = fmaxf(v, 0.f);
