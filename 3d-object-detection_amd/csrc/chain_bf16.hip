@@ -1176,8 +1176,9 @@ __global__ __launch_bounds__(64 * kWaves, FPN_SA_OCC(NJF)) void sa_chain_bf16_ke
 #ifndef FPN_SAP_OCC
 #define FPN_SAP_OCC(np) ((np) == 1 ? 2 : 1)
 #endif
-template <int NT1, int NT2, int NT3, int NP, int KP, bool PRE = false>
-__global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
+// WPB: waves per workgroup (they share the LDS copy of the stream).
+template <int NT1, int NT2, int NT3, int NP, int KP, bool PRE = false, int WPB = kWaves>
+__global__ __launch_bounds__(64 * WPB, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_first_bf16_kernel(const SaParams p, unsigned balls,
                                                                                       unsigned balls_per_wave)
 {
     constexpr int U2 = ((NT2 + 1) / 2) * NT1, U3 = (NT3 / 2) * NT2, U = U2 + U3, C = 32 * NT3;
@@ -1190,14 +1191,14 @@ __global__ __launch_bounds__(64 * kWaves, PRE ? 1 : FPN_SAP_OCC(NP)) void sa_fir
     const unsigned lane = threadIdx.x & 63;
     const int pt = lane & 31, h = lane >> 5;
 
-    for (int i = threadIdx.x; i < U * kUnitVecs; i += 64 * kWaves) wl[i] = p.ws[i];
-    for (int i = threadIdx.x; i < kLdsAhead * kUnitVecs; i += 64 * kWaves) wl[U * kUnitVecs + i] = p.ws[i];
-    for (int i = threadIdx.x; i < 32 * NT2; i += 64 * kWaves) lsh2[i] = p.sh2[i];
-    for (int i = threadIdx.x; i < C; i += 64 * kWaves) lsh3[i] = p.sh3[i];
+    for (int i = threadIdx.x; i < U * kUnitVecs; i += 64 * WPB) wl[i] = p.ws[i];
+    for (int i = threadIdx.x; i < kLdsAhead * kUnitVecs; i += 64 * WPB) wl[U * kUnitVecs + i] = p.ws[i];
+    for (int i = threadIdx.x; i < 32 * NT2; i += 64 * WPB) lsh2[i] = p.sh2[i];
+    for (int i = threadIdx.x; i < C; i += 64 * WPB) lsh3[i] = p.sh3[i];
     for (int i = lane; i < C; i += 64) lmax[i] = 0;
     __syncthreads();
 
-    const unsigned gw = __builtin_amdgcn_readfirstlane(logical_block(1) * kWaves + (threadIdx.x >> 6));
+    const unsigned gw = __builtin_amdgcn_readfirstlane(logical_block(1) * WPB + (threadIdx.x >> 6));
     const unsigned ball0 = gw * balls_per_wave, ball1 = min(balls, ball0 + balls_per_wave);
     if (ball0 >= ball1) return;
     const unsigned cpb = p.ns / (32 * NP);          // rounds per ball
@@ -1838,6 +1839,21 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
     if (groups >= 8) groups -= groups % 8;          // whole rounds over the XCDs (logical_block)
     const unsigned per_wave = (balls + groups * kWaves - 1) / (groups * kWaves);
     const dim3 grid(groups), block(64 * kWaves);
+    if constexpr (NT1 == 4) {
+        // The 128-128-256 stack (it exists with first-layer products only): eight waves of ONE point group each per
+        // workgroup instead of four waves of two.  Two groups per wave need 431 registers - the spill-over lives in
+        // AGPRs and costs ~100 moves per round - one group needs 237, and two waves per SIMD cover each other's
+        // epilogues; the weights are read from LDS twice as often, which LDS has room for (0.484 -> 0.465 ms).
+        constexpr size_t lds8 = lds + kWaves * 32 * NT3 * 4;
+        const unsigned g8 = std::min<unsigned>((unsigned)cus, (balls + 7) / 8);
+        const unsigned gg = g8 >= 8 ? g8 - g8 % 8 : g8;
+        const unsigned pw = (balls + gg * 8 - 1) / (gg * 8);
+        const void *fn8 = reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true, 8>);
+        if (hipFuncSetAttribute(fn8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess)
+            return fail(FPN_E_LAUNCH, "sa_chain_bf16: the device refuses %zu bytes of LDS per workgroup", lds8);
+        hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true, 8>), dim3(gg), dim3(512), lds8, st, p, balls, pw);
+        return check_launch("fpn_sa_chain_bf16");
+    } else
     if (p.pre) {        // (with first-layer products there are no direct feature channels: KP = 4)
         const void *fn = np == 2 ? reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4, true>)
                                  : reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true>);
