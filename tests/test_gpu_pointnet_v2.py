@@ -409,3 +409,37 @@ def test_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
         assert len(st.__dict__.get("_sa_chain_cache", {})) >= 1, "fused kernel not taken"
         assert torch.equal(got["persistent"], got["launch"]), (kind, b, args[0])
         assert got["persistent"].abs().max() > 0
+
+
+@pytest.mark.parametrize("cf,ns,m", [(0, 64, 33), (4, 96, 7), (1, 32, 130)])
+def test_narrow_set_abstraction_kernel(device, cf, ns, m):
+    """The 32-32-64 stack at its own widths (persistent kernel, weights in registers) against the
+    per-layer path and the float64 restatement: several groups of 32 samples per ball (maxima
+    merged across rounds and waves), 0 / 1 / 4 direct feature channels, ball counts that leave
+    waves without work."""
+    from fpn import pointnet_util as U
+    from fpn import variables
+    rng = np.random.RandomState(ns + cf)
+    b, n = 3, 600
+    xyz = rng.uniform(0, 1, (b, n, 3)).astype(np.float32)
+    pts = rng.standard_normal((b, n, cf)).astype(np.float32) if cf else None
+    st = fresh_store(device, seed=3)
+    outs = {}
+    for fuse in (True, True, False):
+        U.FUSE_SA = fuse
+        try:
+            with variables.use_store(st):
+                new_xyz, feat, _ = U.pointnet_sa_module(dev(xyz, device), None if pts is None else dev(pts, device), m, 0.3, ns,
+                                                        [32, 32, 64], None, False, False, None, scope='s')
+        finally:
+            U.FUSE_SA = True
+        if "init" not in outs:
+            outs["init"] = True
+            st.randomize_batch_norm(5)
+            continue
+        outs[fuse] = feat.cpu().numpy()
+    assert len(st.__dict__.get("_sa_chain_cache", {})) == 1 and list(st.__dict__["_sa_chain_cache"].values())[0]["pad"] == (32, 32, 64)
+    wx, wf = P.sa_module(xyz, pts, m, 0.3, ns, [32, 32, 64], False, st.numpy(), "s")
+    np.testing.assert_array_equal(new_xyz.cpu().numpy(), wx)
+    close(outs[True], wf)
+    close(outs[True], outs[False], 1e-4)
