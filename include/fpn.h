@@ -392,13 +392,16 @@ int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const floa
  *   Layer widths c1, c2 (multiples of 64; c2 = 96 is also built for the c1 = 64, c3 = 128,
  *   cf < 32 shape) and c3 (multiple of 128) are the PADDED
  *   widths: a narrower layer is padded by the caller with zero weight columns and
- *   zero scale / shift.  layers: HOST array of 9 device pointers {w,scale,shift} x 3:
+ *   zero scale / shift.  The narrow stack 32,32,64 over cf <= 5 channels has a kernel at its
+ *   own widths.  layers: HOST array of 9 device pointers {w,scale,shift} x 3:
  *     cf < 32 : w1 row-major (3+cf, c1), rows ordered [dx,dy,dz, features];
  *     cf >= 32: cf % 32 == 0, w1 = fpn_tile_weights_reg_f32(jmajor = 0) of the
  *               (cf+32, c1) matrix whose rows are [features, dx,dy,dz, 29 zero rows];
  *     w2 (c1,c2), w3 (c2,c3) in fpn_tile_weights_reg_f32 layout, jmajor = 0.
  *   out (b*m, ldo): columns [0, c3_valid) of row (frustum, ball) receive the running
- *   maximum (atomic max; the caller zeroes them first).  c3_valid: a multiple of 64, <= c3.
+ *   maximum (atomic max; the caller zeroes them first - the persistent kernels that most
+ *   cf < 32 shapes run on store whole rows instead, which a caller must not rely on).
+ *   c3_valid: a multiple of 64, <= c3.
  * fpn_sa_chain_supported tells whether a kernel exists for the padded shape
  * (FPN_E_UNSUPPORTED from fpn_sa_chain_f32 otherwise: use the per-layer path).
  */
