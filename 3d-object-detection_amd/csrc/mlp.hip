@@ -22,7 +22,9 @@
 // fp32 GEMM only by summation order.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
+#include <string>
 
 #include "fpn_common.h"
 
@@ -533,6 +535,217 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_kernel(const MlpP
 }
 
 // ---------------------------------------------------------------------------
+// The same bf16 layer for MANY rows and FEW input channels (the per-point products and
+// feature-propagation layers of the PointNet++ nets: 131 k rows, 128 .. 320 channels in):
+// such a layer is bound by reading x and writing y once, and the kernel above spends most
+// of a workgroup's life waiting - its K loop is two to five steps long, the loads of one
+// step ahead are all it has in flight, and filling and draining that pipeline per 128 rows
+// leaves HBM a quarter used.  Here the workgroups are persistent: a workgroup keeps its 128
+// columns of the weights in LDS for the whole launch (all of K: cout tile x (ldw + 8) bf16)
+// and walks a strided stream of 128-row blocks, whose 64-wide K tiles form ONE sequence of
+// steps across block boundaries.  The loads of steps s + 1 and s + 2 are in flight (two
+// register sets, the loop unrolled by two so that each is addressed statically) while step
+// s multiplies, so the queue never drains between blocks; x tiles go through the same
+// double-buffered bf16 image, one barrier per step.  Same operand slots, same k order and
+// the same epilogue arithmetic as shared_mlp_bf16_kernel: the results are bit-identical.
+// No pooling here (the pooled layers belong to the fused set-abstraction kernels).
+// Workgroup ids are renumbered so that the column tiles of one stream of row blocks run on
+// one XCD and share its L2 copy of x.
+// ---------------------------------------------------------------------------
+// The epilogue of one 128 x 128 block of the persistent kernel, specialised by the kind of group bias (GB: 0 none,
+// 1 one bias row per 32-row tile, 2 one per row, 3 any grouping).  Every block lies wholly inside the rows (the
+// launcher gives a ragged tail to the per-tile kernel), so the only predicate is the lane's column, and the body is
+// straight-line code whose memory-counter bookkeeping the compiler keeps exact.  Loads return in issue order, so a
+// bias value requested here would wait for every x load already in flight: kinds 1 and 2 are requested by
+// stream_bias() at the top of the block's last K step, BEFORE that step's x prefetch, and only read here.
+template <int GB>
+struct StreamBias {
+    static constexpr int N = GB == 2 ? 64 : GB == 1 ? 4 : 1;
+    float v[N];
+};
+
+template <int GB>
+__device__ __forceinline__ void stream_bias(const MlpParams &p, StreamBias<GB> &gb, long row0, int col0, int wm, int wn, int l31,
+                                            int half)
+{
+    if (GB != 1 && GB != 2) return;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = min(col0 + (wn * 2 + b) * 32 + l31, p.cout - 1);      // (a column past the end is never stored)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const long trow = row0 + (wm * 2 + a) * 32 + 4 * half;
+            if (GB == 1) {
+                gb.v[b * 2 + a] = p.group_bias[(trow / p.rows_per_group) * p.cout + col];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    gb.v[(b * 2 + a) * 16 + q] = p.group_bias[(trow + (q & 3) + 8 * (q >> 2)) * p.cout + col];
+            }
+        }
+    }
+}
+
+template <int GB>
+__device__ __forceinline__ void stream_finish(const MlpParams &p, const floatx16 (&acc)[2][2], const StreamBias<GB> &gb,
+                                              const float (&sc)[2], const float (&sh)[2], long row0, int col0, int wm, int wn,
+                                              int l31, int half)
+{
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + (wn * 2 + b) * 32 + l31;
+        if (col < p.cout) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const long trow = row0 + (wm * 2 + a) * 32 + 4 * half;
+                float g3[16];
+                if (GB == 3) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        g3[q] = p.group_bias[((trow + (q & 3) + 8 * (q >> 2)) / p.rows_per_group) * p.cout + col];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const long row = trow + (q & 3) + 8 * (q >> 2);
+                    float v = acc[a][b][q];
+                    if (GB == 1) v += gb.v[b * 2 + a];
+                    if (GB == 2) v += gb.v[(b * 2 + a) * 16 + q];
+                    if (GB == 3) v += g3[q];
+                    v = v * sc[b] + sh[b];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.y[row * p.ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int GB>
+__global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_stream_kernel(const MlpParams p, const int ncb, const int streams,
+                                                                             const int nrb)
+{
+    constexpr int BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds_stream[];
+    const int ldw = (p.cin + kHK - 1) / kHK * kHK;
+    const int ktiles = ldw / kHK;
+    const int wstride = ldw + 8;
+    __bf16 *Wl = lds_stream;                       // [BN][ldw + 8]
+    __bf16 *Xs = lds_stream + BN * wstride;        // [2][BM * kHS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned g = gridDim.x, bi = blockIdx.x;
+    const unsigned blk = (g % 8 == 0) ? (bi % 8) * (g / 8) + bi / 8 : bi;
+    const int col0 = (int)(blk % ncb) * BN;
+    const int stream = (int)(blk / ncb);
+    const __bf16 *wt = reinterpret_cast<const __bf16 *>(p.w);
+
+    // this workgroup's columns of the weights, all of K, once
+    {
+        const int per_col = ldw / 8;
+        for (int e = tid; e < BN * per_col; e += kMlpThreads) {
+            const int c = e / per_col, kv = e - c * per_col;
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (__bf16)0.f;
+            if (col0 + c < p.cout) v = *reinterpret_cast<const bf16x8 *>(wt + (long)(col0 + c) * ldw + 8 * kv);
+            *reinterpret_cast<bf16x8 *>(&Wl[c * wstride + 8 * kv]) = v;
+        }
+    }
+
+    const int mine = stream < nrb ? (nrb - stream + streams - 1) / streams : 0;   // row blocks of this stream
+    const int total = mine * ktiles;
+    const int kq = tid & 15, r = tid >> 4;
+
+    // the cursor of the loads runs two steps ahead of the cursor of the products
+    int ib = stream, ik = 0;
+    // Loads are unconditional so that nothing but the counter orders them (a load under a condition makes the compiler
+    // wait for both sets): channels past cin read the row's last four (and are staged as zeros), the two steps past
+    // the end of the stream read the last row block again (and are never staged).
+    auto issue = [&](float4 (&xr)[8]) {
+        const float *src = p.x + ((long)min(ib, nrb - 1) * BM + r) * p.ldx + min(ik * kHK + 4 * kq, p.cin - 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float4 *>(src + (long)(16 * i) * p.ldx);
+        if (++ik == ktiles) { ik = 0; ib += streams; }
+    };
+    auto stage = [&](const float4 (&xr)[8], int buf, int kt) {
+        __bf16 *xs = Xs + buf * (BM * kHS);
+        const bool live = kt * kHK + 4 * kq < p.cin;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bf16x4 v;
+            v[0] = (__bf16)(live ? xr[i].x : 0.f); v[1] = (__bf16)(live ? xr[i].y : 0.f);
+            v[2] = (__bf16)(live ? xr[i].z : 0.f); v[3] = (__bf16)(live ? xr[i].w : 0.f);
+            *reinterpret_cast<bf16x4 *>(&xs[(r + 16 * i) * kHS + 4 * kq]) = v;
+        }
+    };
+
+    floatx16 acc[2][2];
+    auto clear = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    };
+    clear();
+
+    int cb = stream, ck = 0;
+    // per-column constants of this workgroup's tile, once
+    float sc[2], sh[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = col0 + (wn * 2 + b) * 32 + l31;
+        sc[b] = (col < p.cout && p.scale) ? p.scale[col] : 1.f;
+        sh[b] = (col < p.cout && p.shift) ? p.shift[col] : 0.f;
+    }
+    StreamBias<GB> gb;
+    auto finish = [&]() { stream_finish<GB>(p, acc, gb, sc, sh, (long)cb * BM, col0, wm, wn, l31, half); };
+    auto step = [&](float4 (&xr)[8], int s) {
+        const int buf = s & 1;
+        stage(xr, buf, ck);
+        if (ck + 1 == ktiles) stream_bias<GB>(p, gb, (long)cb * BM, col0, wm, wn, l31, half);
+        issue(xr);                       // step s + 2 into the registers just emptied
+        __syncthreads();                 // image `buf` complete; every wave is done with the products of step s - 1
+        const __bf16 *xs = Xs + buf * (BM * kHS) + (wm * 64 + l31) * kHS + 8 * half;
+        const __bf16 *ws = Wl + (wn * 64 + l31) * wstride + ck * kHK + 8 * half;
+#pragma unroll
+        for (int u = 0; u < kHK / 16; ++u) {
+            bf16x8 av[2], bv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = *reinterpret_cast<const bf16x8 *>(xs + a * 32 * kHS + 16 * u);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bv[b] = *reinterpret_cast<const bf16x8 *>(ws + b * 32 * wstride + 16 * u);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (++ck == ktiles) {
+            finish();
+            clear();
+            ck = 0;
+            cb += streams;
+        }
+    };
+
+    float4 xa[8], xb[8];
+    issue(xa);
+    issue(xb);
+    // (whole pairs in the loop and the odd step after it: a conditional second step would make the order of the two
+    // sets' loads unknown at the top of the loop, and the compiler would then wait for both)
+    int s = 0;
+    for (; s + 1 < total; s += 2) {
+        step(xa, s);
+        step(xb, s + 1);
+    }
+    if (s < total) step(xa, s);
+}
+
+// ---------------------------------------------------------------------------
 // Few rows (fully connected layers: one row per frustum; the small feature-propagation
 // and group-all layers of the PointNet++ variant): 128-row tiles would leave most of
 // the chip idle and a K loop through LDS with a barrier per step leaves each
@@ -813,6 +1026,13 @@ int static_scratch(float **out)
     return FPN_OK;
 }
 
+// FPN_BF16_MLP=tile keeps the per-tile kernel for every bf16 layer (a measurement switch; the twin of the tests)
+inline bool mlp_bf16_stream()
+{
+    const char *e = std::getenv("FPN_BF16_MLP");
+    return !(e && std::string(e) == "tile");
+}
+
 int check_common(const char *who, long rows, int cin, int cout, const float *x, int ldx, const float *w,
                  int pool_rows, const float *y, int ldy, const void *workspace, size_t workspace_bytes)
 {
@@ -909,6 +1129,49 @@ int fpn_shared_mlp_bf16(long rows, int cin, int cout, const float *x, int ldx, c
     hipStream_t st = as_stream(stream);
     const long nblk = ((rows + kBM - 1) / kBM) * ((cout + 127) / 128);
     FPN_REQUIRE(nblk <= INT32_MAX, "shared_mlp_bf16: grid too large");
+    {
+        // many rows, few input channels, no pooling: the persistent kernel with the weights resident in LDS takes the
+        // whole 128-row blocks, the per-tile kernel below a ragged tail
+        const int ldw = (cin + kHK - 1) / kHK * kHK, ncb = (cout + 127) / 128;
+        const long nrb = rows / kBM, tail = rows - nrb * kBM;
+        const size_t lds = ((size_t)128 * (ldw + 8) + 2 * (size_t)kBM * kHS) * sizeof(__bf16);
+        const int gbmode = !group_bias ? 0 : (p.rows_per_group % 32 == 0) ? 1 : (p.rows_per_group == 1) ? 2 : 3;
+        const bool tail_ok = tail == 0 || gbmode == 0 || (nrb * kBM) % p.rows_per_group == 0;
+        int dev = 0, cus = 0;
+        if (pool_rows == 0 && nrb >= 1024 && nrb <= INT32_MAX && lds <= 160 * 1024 && cin % 4 == 0 && ldx % 4 == 0 && tail_ok &&
+            (reinterpret_cast<uintptr_t>(x) & 15) == 0 && mlp_bf16_stream() && hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) {
+            // two workgroups a CU when LDS allows (at most 256 registers), one with a bias row per row (its 64 bias
+            // registers make 318)
+            int streams = cus * (gbmode == 2 ? 1 : (int)std::min<size_t>(2, (160 * 1024) / lds)) / ncb;
+            streams -= streams % 8;                        // (whole rounds over the XCDs: the kernel's renumbering)
+            if (streams >= 8) {
+                const void *fn = gbmode == 0 ? reinterpret_cast<const void *>(&shared_mlp_bf16_stream_kernel<0>)
+                               : gbmode == 1 ? reinterpret_cast<const void *>(&shared_mlp_bf16_stream_kernel<1>)
+                               : gbmode == 2 ? reinterpret_cast<const void *>(&shared_mlp_bf16_stream_kernel<2>)
+                                             : reinterpret_cast<const void *>(&shared_mlp_bf16_stream_kernel<3>);
+                if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return fail(FPN_E_LAUNCH, "shared_mlp_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
+                MlpParams q = p;
+                q.rows = nrb * kBM;
+                const dim3 grid((unsigned)(streams * ncb)), block(kMlpThreads);
+                switch (gbmode) {
+                case 0: hipLaunchKernelGGL(shared_mlp_bf16_stream_kernel<0>, grid, block, lds, st, q, ncb, streams, (int)nrb); break;
+                case 1: hipLaunchKernelGGL(shared_mlp_bf16_stream_kernel<1>, grid, block, lds, st, q, ncb, streams, (int)nrb); break;
+                case 2: hipLaunchKernelGGL(shared_mlp_bf16_stream_kernel<2>, grid, block, lds, st, q, ncb, streams, (int)nrb); break;
+                default: hipLaunchKernelGGL(shared_mlp_bf16_stream_kernel<3>, grid, block, lds, st, q, ncb, streams, (int)nrb); break;
+                }
+                rc = check_launch("fpn_shared_mlp_bf16(stream)");
+                if (rc != FPN_OK || tail == 0) return rc;
+                p.rows = tail;
+                p.x = x + nrb * kBM * (long)ldx;
+                p.y = y + nrb * kBM * (long)ldy;
+                if (group_bias) p.group_bias = group_bias + (nrb * kBM / p.rows_per_group) * (long)cout;
+                hipLaunchKernelGGL(shared_mlp_bf16_kernel, dim3((unsigned)ncb), dim3(kMlpThreads), 0, st, p);
+                return check_launch("fpn_shared_mlp_bf16(tail)");
+            }
+        }
+    }
     hipLaunchKernelGGL(shared_mlp_bf16_kernel, dim3((unsigned)nblk), dim3(kMlpThreads), 0, st, p);
     rc = check_launch("fpn_shared_mlp_bf16");
     if (rc != FPN_OK) return rc;

@@ -330,6 +330,51 @@ def test_bf16_tiled_layer(device, rows, cin, cout, pool, gb):
             assert scaled_err(got.cpu().numpy(), want32.cpu().numpy()) <= BF16_RTOL
 
 
+@pytest.mark.parametrize("rows,ldx,cin,cout,gb,relu", [
+    (131072, 128, 128, 128, 0, True),        # whole blocks, two K tiles
+    (131072 + 77, 324, 320, 320, 0, False),  # three column tiles (the last one half full), ragged tail of rows
+    (131072 + 128, 320, 320, 128, 1, True),  # a bias row per row
+    (140000, 136, 132, 200, 128, True),      # cin off the K tile, a bias row per 128 rows, ragged tail
+    (131072 + 96, 64, 64, 64, 3, True),      # any grouping (131072 is not a multiple of 3: the per-tile kernel takes it all)
+    (131072 + 96, 68, 68, 72, 2, True),      # any grouping with a tail that starts on a group boundary
+])
+def test_bf16_streamed_layer_bit_for_bit(device, monkeypatch, rows, ldx, cin, cout, gb, relu):
+    """Many rows, few input channels: fpn_shared_mlp_bf16 runs the persistent kernel (the weights resident in LDS,
+    one pipeline of x tiles across row blocks) on the whole 128-row blocks and the per-tile kernel on a ragged tail.
+    Same operand slots, k order and epilogue arithmetic: it must equal the per-tile kernel (FPN_BF16_MLP=tile) bit
+    for bit, and on small-integer data the fp32 kernel too."""
+    from fpn import ops
+    rng = np.random.RandomState(rows % 1000 + cin)
+    for kind in ("int", "real"):
+        if kind == "int":
+            x = rng.randint(-3, 4, (rows, ldx)).astype(np.float32)
+            w = rng.randint(-2, 3, (cin, cout)).astype(np.float32)
+            scale = rng.randint(1, 3, cout).astype(np.float32)
+            shift = rng.randint(-4, 5, cout).astype(np.float32)
+        else:
+            x = rng.standard_normal((rows, ldx)).astype(np.float32)
+            w = (rng.standard_normal((cin, cout)) * cin ** -0.5).astype(np.float32)
+            scale = (rng.random_sample(cout) + 0.5).astype(np.float32)
+            shift = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        if ldx > cin:
+            x[:, cin:] = np.nan                  # columns past cin are not the layer's: they must not be read into it
+        bias = None
+        if gb:
+            groups = -(-rows // gb)
+            bias = (rng.randint(-3, 4, (groups, cout)) if kind == "int" else rng.standard_normal((groups, cout))).astype(np.float32)
+        xd, wd = dev(x, device), dev(w, device)
+        wt = ops.pack_mlp_bf16(wd)
+        kw = dict(relu=relu, group_bias=None if bias is None else dev(bias, device), rows_per_group=gb)
+        monkeypatch.setenv("FPN_BF16_MLP", "tile")
+        want = ops.shared_mlp(xd[:, :cin], wd, dev(scale, device), dev(shift, device), wt_bf16=wt, **kw)
+        monkeypatch.delenv("FPN_BF16_MLP", raising=False)
+        got = ops.shared_mlp(xd[:, :cin], wd, dev(scale, device), dev(shift, device), wt_bf16=wt, **kw)
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, want)
+        if kind == "int":
+            assert torch.equal(got, ops.shared_mlp(xd[:, :cin], wd, dev(scale, device), dev(shift, device), **kw))
+
+
 def test_bf16_interpolation_output_feeds_the_head_bit_for_bit(device):
     """Under bf16 the last feature propagation hands its interpolated features to the fused
     head kernel as bf16 (fpn_three_nn_interpolate_bf16 -> fpn_fp_head_chain_bf16x) instead of
