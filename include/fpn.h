@@ -200,6 +200,13 @@ size_t fpn_shared_mlp_workspace_bytes(long rows, int cout, int pool_rows);
  *   wt: the weights transposed and converted by fpn_mlp_pack_bf16: (cout, ldw) bf16,
  *   ldw = cin rounded up to a multiple of 64, zeros beyond cin; 16-byte aligned.
  *   Everything else as fpn_shared_mlp_f32.
+ * Two kernels, one result: with no pooling, at least 131072 rows, cin a multiple of 4 and at
+ * most 448 and x 16-byte aligned with ldx a multiple of 4, persistent workgroups keep their
+ * columns of wt in LDS and stream the whole 128-row blocks of x through one pipeline (a
+ * ragged tail of rows goes to the per-tile kernel in a second launch - with a group bias
+ * only if the tail starts on a group boundary); every other layer runs the per-tile kernel.  Both use the same operand slots, k order and epilogue
+ * arithmetic: the choice never changes a bit of y.  FPN_BF16_MLP=tile in the environment
+ * keeps the per-tile kernel everywhere (a measurement switch).
  */
 int fpn_mlp_pack_bf16(int cin, int cout, const float *w, void *wt, void *stream);
 int fpn_shared_mlp_bf16(long rows, int cin, int cout, const float *x, int ldx, const void *wt,
