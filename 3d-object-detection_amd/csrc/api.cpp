@@ -22,7 +22,7 @@ int fail(int code, const char *fmt, ...)
 
 extern "C" {
 
-int fpn_abi_version(void) { return 16; }
+int fpn_abi_version(void) { return 17; }
 
 const char *fpn_last_error_string(void) { return fpn::error_buffer(); }
 

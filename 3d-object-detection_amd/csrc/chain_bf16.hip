@@ -2111,6 +2111,12 @@ int fpn_sa_chain_bf16_supported(int cf, int c1, int c2, int c3)
     return fpn_sa_chain_supported(cf, c1, c2, c3);
 }
 
+int fpn_sa_chain_bf16_overwrites(long rows, int cf, int c1, int c2, int c3)
+{
+    // (the dispatch of sa_chain_bf16 below: the persistent kernels store a ball's pooled row, the others merge maxima)
+    return fpn_sa_chain_bf16_supported(cf, c1, c2, c3) && cf < 32 && sa_persistent() && rows < (1L << 31);
+}
+
 static int sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                          const float *new_xyz, const float *feat, const void *feat_packed, const float *pre, int ld_pre,
                          const int *idx,

@@ -1573,6 +1573,14 @@ int fpn_sa_chain_supported(int cf, int c1, int c2, int c3)
            (njf == 4 && t1 == 4 && t2 == 4 && t3 == 8);
 }
 
+int fpn_sa_chain_overwrites(long rows, int cf, int c1, int c2, int c3)
+{
+    if (!fpn_sa_chain_supported(cf, c1, c2, c3) || cf >= 32 || c1 == 32) return 0;
+    const int t1 = c1 / 32, t2 = c2 / 32;
+    // (the dispatch of sa_chain_f32 below: the persistent kernels store a ball's pooled row, the others merge maxima)
+    return ((t1 == 2 && t2 <= 3) || t1 == 4) && sa_persistent_f32() && rows < (1L << 31);
+}
+
 static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                         const float *new_xyz, const float *feat, const float *pre, int ld_pre, const int *idx,
                         const float *const *layers, float *out, int ldo, int c3_valid, void *stream)

@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class FpnError(RuntimeError):
@@ -56,6 +56,8 @@ SIGNATURES = {
     "fpn_tile_weights_reg_f32": [_i, _i, _i, _vp, _vp, _vp],
     "fpn_sa_chain_supported": [_i, _i, _i, _i],
     "fpn_sa_chain_bf16_supported": [_i, _i, _i, _i],
+    "fpn_sa_chain_overwrites": [_l, _i, _i, _i, _i],
+    "fpn_sa_chain_bf16_overwrites": [_l, _i, _i, _i, _i],
     "fpn_sa_chain_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_sa_chain_pre_f32": [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "fpn_v1_seg_head_f32": [_l, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],

@@ -228,6 +228,10 @@ def _sa_chain_plan(store, names, cf, widths, bn, xyz_first):
 # reference's order of operations; the same results up to fp32 rounding).
 HOIST_FEATURES = True
 
+# A test switch: fill with NaN every set-abstraction output that is handed to a kernel
+# without being cleared (the kernel is trusted to store all of it).
+POISON_UNCLEARED = False
+
 # Under SA_PRECISION = "bf16": point features wider than 32 channels are converted to the
 # kernel's operand form once per module instead of once per gathered row (False: gathered as
 # float and converted in the kernel - same results).
@@ -263,13 +267,18 @@ def _sa_chain(xyz, new_xyz, points, idx, widths, scope_fmt, bn, out2d, xyz_first
     plan = _sa_chain_plan(store, names, cf, widths, bn, xyz_first)
     if plan is None:
         return False
-    if not zeroed:
-        out2d.zero_()
     pad = plan["pad"]
+    hoisted = "w1f" in plan
+    if not zeroed:
+        # the persistent kernels store every ball's row; the others merge maxima into a cleared buffer
+        ask = _lib.load().fpn_sa_chain_bf16_overwrites if "stream" in plan else _lib.load().fpn_sa_chain_overwrites
+        if not ask(b * m * ns, 0 if hoisted else cf, pad[0], pad[1], pad[2]):
+            out2d.zero_()
+        elif POISON_UNCLEARED:
+            out2d.fill_(float("nan"))
     ldo = out2d.stride(0) if out2d.shape[0] > 1 else max(out2d.stride(0), out2d.shape[1])
     obs = ops.launch_observer
     tok = None
-    hoisted = "w1f" in plan
     if obs is not None:       # algorithmic work: the unpadded layer widths (hoisted: the features' rows of the
         # first layer are another launch's work, once per point)
         macs = (3 + (0 if hoisted else cf)) * widths[0] + widths[0] * widths[1] + widths[1] * widths[2]
@@ -475,8 +484,8 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
         b, m = new_xyz.shape[0], new_xyz.shape[1]
         width = sum(w[-1] for w in mlp_list)
-        # (one clear for all scales: the fused kernels merge their maxima into it)
-        out = torch.zeros((b * m, width), dtype=torch.float32, device=xyz.device)
+        # (every scale fills its columns: a fused kernel that merges maxima clears them first, _sa_chain)
+        out = torch.empty((b * m, width), dtype=torch.float32, device=xyz.device)
         shared = {}         # what the scales have in common: the packed feature table, the first-layer products
         if FUSE_SA and points is not None and use_xyz:
             points = points.contiguous()
@@ -491,7 +500,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             if (points is None or use_xyz) and FUSE_SA and \
                     _sa_chain(xyz, new_xyz, None if points is None else points.contiguous(), idx, mlp_list[i],
                               'conv%d_' % i + '%d', bn, out[:, col:col + w_i], xyz_first=False,
-                              zeroed=True, shared=shared):                                                      # :176-192 in one kernel
+                              shared=shared):                                                      # :176-192 in one kernel
                 col += w_i
                 continue
             if points is not None and use_xyz:

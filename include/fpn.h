@@ -406,8 +406,8 @@ int fpn_v1_obj_chain_f32(long rows, int m, int box, const float *obj, const floa
  *               (cf+32, c1) matrix whose rows are [features, dx,dy,dz, 29 zero rows];
  *     w2 (c1,c2), w3 (c2,c3) in fpn_tile_weights_reg_f32 layout, jmajor = 0.
  *   out (b*m, ldo): columns [0, c3_valid) of row (frustum, ball) receive the running
- *   maximum (atomic max; the caller zeroes them first - the persistent kernels that most
- *   cf < 32 shapes run on store whole rows instead, which a caller must not rely on).
+ *   maximum (atomic max; the caller zeroes them first - unless fpn_sa_chain_overwrites says
+ *   that this call runs a persistent kernel, which stores whole rows instead).
  *   c3_valid: a multiple of 64, <= c3.
  * fpn_sa_chain_supported tells whether a kernel exists for the padded shape
  * (FPN_E_UNSUPPORTED from fpn_sa_chain_f32 otherwise: use the per-layer path).
@@ -523,6 +523,16 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
  * all 32 points per frustum - idx = 0..31, new_xyz = 0 - over 640 features through
  * 128-256-1024 and over 256 features through 256-256-512). */
 int fpn_sa_chain_bf16_supported(int cf, int c1, int c2, int c3);
+/* The kernels of fpn_sa_chain_f32 / _pre_f32 (fpn_sa_chain_overwrites) and of fpn_sa_chain_bf16 /
+ * _pre_bf16 / _bf16p (fpn_sa_chain_bf16_overwrites) come in two kinds: some MERGE their maxima
+ * into out (atomic max on values >= 0), so out must start at zero; the persistent ones STORE
+ * every ball's pooled row, all c3_valid columns of it, so out need not be initialised.  These
+ * queries tell which kind a call with rows = b*m*ns and the same cf and widths runs: 1 = stores
+ * whole rows, 0 = merges (or the shape has no kernel).  The answer depends on the process's
+ * environment switches: ask at call time.  A zeroed out is always correct.  No counterpart in
+ * the reference (tf.reduce_max of models/pointnet_util.py:128, :192 writes a new tensor). */
+int fpn_sa_chain_overwrites(long rows, int cf, int c1, int c2, int c3);
+int fpn_sa_chain_bf16_overwrites(long rows, int cf, int c1, int c2, int c3);
 int fpn_sa_chain_bf16(int b, int n, int m, int ns, int cf, int c1, int c2, int c3, const float *xyz,
                       const float *new_xyz, const float *feat, const int *idx, const void *wstream,
                       const float *const *consts, float *out, int ldo, int c3_valid, void *stream);

@@ -380,6 +380,7 @@ def test_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
     products."""
     from fpn import pointnet_util as U
     from fpn import variables
+    monkeypatch.setattr(U, "POISON_UNCLEARED", True)      # outputs the persistent kernels are trusted to fill start as NaN
     rng = np.random.RandomState(11)
     cases = [("msg", 3, 1024, 1, (64, [0.1, 0.2, 0.4], [32, 64, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]])),
              ("ssg", 2, 512, 0, (5, 0.3, 32, [64, 96, 128])),
@@ -409,6 +410,32 @@ def test_persistent_set_abstraction_bit_for_bit(device, monkeypatch):
         assert len(st.__dict__.get("_sa_chain_cache", {})) >= 1, "fused kernel not taken"
         assert torch.equal(got["persistent"], got["launch"]), (kind, b, args[0])
         assert got["persistent"].abs().max() > 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_v2_outputs_do_not_depend_on_uncleared_buffers(device, monkeypatch, precision):
+    """Set-abstraction outputs are cleared only for the kernels that merge maxima into them
+    (fpn_sa_chain_overwrites / fpn_sa_chain_bf16_overwrites say which): with every uncleared
+    output filled with NaN first, the v2 net gives the same bits."""
+    from fpn import pointnet_util as U
+    from fpn import synthetic, variables
+    from fpn.models import frustum_pointnets_v2 as M2
+    monkeypatch.setattr(U, "SA_PRECISION", precision)
+    pc, one_hot = synthetic.make_frustums(3, 2048, 4, seed=4)
+    pc[..., :3] *= 0.05
+    st = fresh_store(device, seed=9)
+    with variables.use_store(st):
+        M2.get_model(dev(pc, device), dev(one_hot, device), False)
+    st.randomize_batch_norm(3)
+    got = {}
+    for poison in (False, True):
+        monkeypatch.setattr(U, "POISON_UNCLEARED", poison)
+        with variables.use_store(st):
+            ep = M2.get_model(dev(pc, device), dev(one_hot, device), False)
+        got[poison] = {k: ep[k].clone() for k in ("mask_logits", "center_delta", "box_output")}
+    for k, v in got[True].items():
+        assert torch.isfinite(v).all(), k
+        assert torch.equal(v, got[False][k]), k
 
 
 @pytest.mark.parametrize("cf,ns,m", [(0, 64, 33), (4, 96, 7), (1, 32, 130)])

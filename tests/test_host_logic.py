@@ -52,6 +52,17 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.fpn_sa_chain_supported(0, 128, 128, 256) == 1 and lib.fpn_sa_chain_supported(0, 128, 128, 128) == 0
     assert lib.fpn_sa_chain_bf16_supported(640, 128, 256, 1024) == 1 and lib.fpn_sa_chain_supported(640, 128, 256, 1024) == 0
     assert lib.fpn_sa_chain_bf16_supported(1, 64, 96, 128) == 1 and lib.fpn_sa_chain_bf16_supported(320, 64, 96, 128) == 0
+    # ... and which of them store whole rows of `out` (persistent kernels) rather than merge maxima into a cleared one
+    assert lib.fpn_sa_chain_overwrites(1 << 20, 1, 64, 64, 128) == 1 and lib.fpn_sa_chain_overwrites(1 << 20, 0, 128, 128, 256) == 1
+    assert lib.fpn_sa_chain_overwrites(1 << 20, 1, 32, 32, 64) == 0 and lib.fpn_sa_chain_overwrites(1 << 20, 0, 64, 128, 128) == 0
+    assert lib.fpn_sa_chain_overwrites(1 << 20, 320, 64, 64, 128) == 0 and lib.fpn_sa_chain_overwrites(1 << 31, 1, 64, 64, 128) == 0
+    assert lib.fpn_sa_chain_bf16_overwrites(1 << 20, 1, 64, 96, 128) == 1 and lib.fpn_sa_chain_bf16_overwrites(1 << 20, 640, 128, 256, 1024) == 0
+    assert lib.fpn_sa_chain_bf16_overwrites(1 << 20, 1, 32, 32, 64) == 0          # (no bf16 kernel at all)
+    os.environ["FPN_BF16_SA"] = os.environ["FPN_F32_SA"] = "launch"               # the switches are read at every call
+    try:
+        assert lib.fpn_sa_chain_overwrites(1 << 20, 1, 64, 64, 128) == 0 and lib.fpn_sa_chain_bf16_overwrites(1 << 20, 1, 64, 96, 128) == 0
+    finally:
+        del os.environ["FPN_BF16_SA"], os.environ["FPN_F32_SA"]
     # first-layer products: aligned, a row stride of at least c1 floats, no wide direct features beside them
     assert lib.fpn_sa_chain_pre_f32(1, 8, 2, 32, 0, 64, 64, 128, P, P, None, ctypes.c_void_p(20), 64, P, P, P, 128, 128,
                                     None) == -1
