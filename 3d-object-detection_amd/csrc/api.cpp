@@ -22,7 +22,7 @@ int fail(int code, const char *fmt, ...)
 
 extern "C" {
 
-int fpn_abi_version(void) { return 17; }
+int fpn_abi_version(void) { return 18; }
 
 const char *fpn_last_error_string(void) { return fpn::error_buffer(); }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.abspath(os.environ["FPN_LIB_PATH"]) if os.environ.get("FPN_LI
 
 FPN_OK = 0
 STATIC_SCRATCH_BYTES = 8 << 20   # FPN_STATIC_SCRATCH_BYTES of include/fpn.h
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class FpnError(RuntimeError):
@@ -83,6 +83,7 @@ SIGNATURES = {
     "fpn_box3d_iou_f64": [_l, _vp, _l, _vp, _l, _vp, _vp],
     "fpn_box3d_intersection_f64": [_l, _vp, _l, _vp, _l, _vp, _vp, _vp],
     "fpn_box3d_best_overlap_f64": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fpn_detection_records": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_mask_gather": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 

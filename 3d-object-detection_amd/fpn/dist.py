@@ -13,6 +13,9 @@ import torch.distributed as dist
 
 # box vector (59) | stage1_center (3) | mask_xyz_mean (3)
 RECORD = 59 + 3 + 3
+# detection record (fpn_detection_records): h w l tx ty tz ry score | classes, residuals,
+# centre, positive count, class probabilities - float64
+DETECTION = 20
 
 
 def shard_range(total, rank, world):
@@ -29,6 +32,29 @@ def pack_results(end_points, with_logits=False):
         b = end_points["mask_logits"].shape[0]
         parts.append(end_points["mask_logits"].reshape(b, -1))
     return torch.cat(parts, dim=1).contiguous()
+
+
+def pack_detections(end_points, rot_angle=None):
+    """end_points -> (B, DETECTION) float64 detection records (label fields, score, picks):
+    the finished detections, 160 bytes per frustum, computed on the device from the logits
+    the raw record would have to carry along (8-16 KB per frustum) to yield a score."""
+    from . import inference
+    rec, _ = inference.detection_records(end_points["mask_logits"].contiguous(), end_points["box_output"].contiguous(),
+                                         end_points["stage1_center"].contiguous(), rot_angle)
+    return rec
+
+
+def gather_detections(records, total=None, group=None, out=None, async_op=False):
+    """One all-gather of the ranks' detection records -> (total, DETECTION) float64 on
+    every rank in global frustum order.  `total`: size of the global batch when the
+    shards are ragged (shard_range blocks)."""
+    if records.dim() != 2 or records.shape[1] != DETECTION:
+        raise ValueError("expected a (frustums, %d) detection table, got %s" % (DETECTION, tuple(records.shape)))
+    if total is None:
+        return gather_results(records.contiguous(), group, out, async_op=async_op)
+    if async_op:
+        raise ValueError("the ragged detection gather has no asynchronous form")
+    return gather_ragged(records.contiguous(), total, group)
 
 
 def unpack_results(records, num_point=None):
@@ -101,12 +127,15 @@ def _as_host_tensor(a):
     return torch.from_numpy(a).contiguous()       # shares numpy's memory
 
 
-def run_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False):
+def run_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False, detections=False,
+                 rot_angle=None):
     """A scene set larger than one batch: walk this rank's frustums in chunks of `chunk`
     with the next chunk's host -> device copy overlapped with the current chunk's compute.
 
     point_cloud (B,N,C) and one_hot (B,3): float32 HOST arrays or tensors; forward(pc, oh)
-    -> end_points on `device`; returns the (B, RECORD [+2N]) result records on `device`.
+    -> end_points on `device`; returns the (B, RECORD [+2N]) result records on `device`, or
+    with detections=True the (B, DETECTION) float64 detection records (rot_angle: (B,)
+    float32 host array of the frustums' rotation angles, None = unrotated).
 
     Two device slots and two pinned staging slots; per chunk: the host copies its rows into
     the pinned slot (skipped when the source is pinned already), a COPY stream moves them
@@ -121,14 +150,21 @@ def run_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False
         raise ValueError("chunk must be positive")
     total, n, c = pc_h.shape
     device = torch.device(device)
-    width = RECORD + (2 * n if with_logits else 0)
-    records = torch.empty((total, width), dtype=torch.float32, device=device)
+    if detections and with_logits:
+        raise ValueError("detection records do not carry logits")
+    if detections:
+        records = torch.empty((total, DETECTION), dtype=torch.float64, device=device)
+        rot_d = None if rot_angle is None else _as_host_tensor(rot_angle).to(device, torch.float32).reshape(total)
+        pack = lambda ep, lo, hi: pack_detections(ep, None if rot_d is None else rot_d[lo:hi])      # noqa: E731
+    else:
+        records = torch.empty((total, RECORD + (2 * n if with_logits else 0)), dtype=torch.float32, device=device)
+        pack = lambda ep, lo, hi: pack_results(ep, with_logits)                                       # noqa: E731
     if total == 0:
         return records
     if device.type != "cuda":
         for lo in range(0, total, chunk):
             hi = min(total, lo + chunk)
-            records[lo:hi] = pack_results(forward(pc_h[lo:hi].to(device), oh_h[lo:hi].to(device)), with_logits)
+            records[lo:hi] = pack(forward(pc_h[lo:hi].to(device), oh_h[lo:hi].to(device)), lo, hi)
         return records
 
     rows = min(chunk, total)
@@ -174,22 +210,25 @@ def run_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False
             hi = min(total, lo + chunk)
             slot, k = i % 2, hi - lo
             main.wait_event(copied[slot])
-            records[lo:hi] = pack_results(forward(dev_pc[slot][:k], dev_oh[slot][:k]), with_logits)
+            records[lo:hi] = pack(forward(dev_pc[slot][:k], dev_oh[slot][:k]), lo, hi)
             consumed[slot].record(main)
         # the slots must outlive the queued work that reads them
         main.synchronize()
     return records
 
 
-def run_sharded_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False, group=None):
+def run_sharded_streamed(forward, point_cloud, one_hot, chunk, device, with_logits=False, group=None,
+                         detections=False, rot_angle=None):
     """The whole scene set on every rank's host (or at least this rank's block of it):
     rank r streams frustums shard_range(B, r, W) through `forward` and the records of all
-    ranks are gathered once at the end -> (B, RECORD [+2N]) on every rank."""
+    ranks are gathered once at the end -> (B, RECORD [+2N]) on every rank, or with
+    detections=True the (B, DETECTION) detection records."""
     total = point_cloud.shape[0]
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
     lo, hi = shard_range(total, rank, world)
-    rec = run_streamed(forward, point_cloud[lo:hi], one_hot[lo:hi], chunk, device, with_logits)
+    rec = run_streamed(forward, point_cloud[lo:hi], one_hot[lo:hi], chunk, device, with_logits, detections,
+                       None if rot_angle is None else rot_angle[lo:hi])
     return gather_ragged(rec, total, group)

@@ -1,9 +1,68 @@
 """Post-processing of the detector outputs: counterpart of the arithmetic of
-scripts/test.py:inference (:122-162).  Takes the six `det_model` outputs and returns
-the reference's seven arrays.  Like the reference this runs on the host in numpy
-float64 buffers (np.zeros default dtype, test.py:125-131); it is per-frustum scalar
-work, not part of the device path."""
+scripts/test.py:inference (:122-162) and of the label conversion its writer calls
+(scripts/provider.py:366-373).
+
+Device path: `detection_records` runs fpn_detection_records on the network's outputs
+(one wave per frustum: soft-max scores, class picks, residual picks, label fields
+h,w,l,tx,ty,tz,ry in float64) and the (B, 20) float64 record is all that has to leave the
+GPU - or travel between GPUs.  `inference` and `test` use it whenever the model offers
+`detect` (the models of this package do).  `postprocess` is the same arithmetic on host
+arrays for callers that only hold the six `det_model` outputs in numpy."""
 import numpy as np
+
+# columns of a detection record (FPN_DETECTION_RECORD doubles, include/fpn.h)
+RECORD = 20
+LABEL = slice(0, 7)          # h, w, l, tx, ty, tz, ry
+SCORE, HEADING_CLS, SIZE_CLS, HEADING_RES = 7, 8, 9, 10
+SIZE_RES = slice(11, 14)
+CENTER = slice(14, 17)
+POSITIVES, HEADING_PROB, SIZE_PROB = 17, 18, 19
+
+
+def detection_records(mask_logits, box_output, stage1_center, rot_angle=None, want_seg=False):
+    """Network outputs on the device -> (records (B,20) float64, seg_bits (B,ceil(N/32))
+    int32 or None), both on the device.  mask_logits (B,N,2), box_output (B,59),
+    stage1_center (B,3), rot_angle (B,) float32 or None (frustums not rotated)."""
+    import torch
+    from . import _lib
+    _lib.require_device_tensor("mask_logits", mask_logits, torch.float32, 3, 2)
+    _lib.require_device_tensor("box_output", box_output, torch.float32, 2, 59)
+    _lib.require_device_tensor("stage1_center", stage1_center, torch.float32, 2, 3)
+    b, n, _ = mask_logits.shape
+    if box_output.shape[0] != b or stage1_center.shape[0] != b:
+        raise ValueError("mask_logits, box_output and stage1_center must hold the same number of frustums")
+    if n < 1:
+        raise ValueError("detection_records needs at least one point per frustum")
+    if rot_angle is not None:
+        _lib.require_device_tensor("rot_angle", rot_angle, torch.float32, 1)
+        if rot_angle.shape[0] != b:
+            raise ValueError("rot_angle must hold one angle per frustum")
+    dev = _lib.same_device(mask_logits, box_output, stage1_center, rot_angle)
+    records = torch.empty((b, RECORD), dtype=torch.float64, device=dev)
+    seg = torch.empty((b, (n + 31) // 32), dtype=torch.int32, device=dev) if want_seg else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().fpn_detection_records(
+            b, n, _lib.ptr(mask_logits), _lib.ptr(box_output), _lib.ptr(stage1_center), _lib.ptr(rot_angle),
+            _lib.ptr(records), _lib.ptr(seg), _lib.stream_of(mask_logits)))
+    return records, seg
+
+
+def unpack_seg_bits(seg_bits, n):
+    """(B, ceil(n/32)) mask words (device tensor or array) -> (B,n) int64 0/1 host array,
+    the `np.argmax(logits, 2)` of scripts/test.py:162."""
+    words = seg_bits.cpu().numpy() if hasattr(seg_bits, "cpu") else np.asarray(seg_bits)
+    bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), axis=1, bitorder="little")
+    return bits[:, :n].astype(np.int64)
+
+
+def outputs_from_records(records, seg_bits=None, num_point=None):
+    """Detection records -> the seven arrays scripts/test.py:inference returns (:162):
+    (seg (B,N) or None, centers (B,3), heading_cls, heading_res, size_cls, size_res (B,3),
+    scores), float64 / int64 host arrays."""
+    rec = records.cpu().numpy() if hasattr(records, "cpu") else np.asarray(records)
+    seg = None if seg_bits is None else unpack_seg_bits(seg_bits, num_point)
+    return (seg, rec[:, CENTER].copy(), rec[:, HEADING_CLS].astype(np.int64), rec[:, HEADING_RES].copy(),
+            rec[:, SIZE_CLS].astype(np.int64), rec[:, SIZE_RES].copy(), rec[:, SCORE].copy())
 
 
 def softmax(x):
@@ -61,18 +120,38 @@ def detection_lines(id_list, type_list, box2d_list, center_list, heading_cls_lis
     return results
 
 
+def detection_lines_from_records(id_list, type_list, box2d_list, records):
+    """The same label lines from detection records (columns 0..7 = h w l tx ty tz ry score):
+    the label conversion has already run on the device, only the formatting is left."""
+    from . import provider
+    onehot2type = {v: k for k, v in provider.g_type2onehotclass.items()}
+    rec = records.cpu().numpy() if hasattr(records, "cpu") else np.asarray(records)
+    results = {}
+    for i in range(rec.shape[0]):
+        box2d = box2d_list[i]
+        line = onehot2type[type_list[i]] + " -1 -1 -10 "
+        line += "%f %f %f %f " % (box2d[0], box2d[1], box2d[2], box2d[3])
+        line += "%f %f %f %f %f %f %f %f" % tuple(rec[i, :8])
+        results.setdefault(id_list[i], []).append(line)
+    return results
+
+
 def write_detection_results(result_dir, id_list, type_list, box2d_list, center_list, heading_cls_list,
                             heading_res_list, size_cls_list, size_res_list, rot_angle_list, score_list,
-                            csv_path="results_output.csv"):
+                            csv_path="results_output.csv", records=None):
     """Write <result_dir>/data/<id>.txt label files and the id -> lines CSV
     (scripts/test.py:51-90; the reference always writes the CSV into the working
-    directory, pass csv_path=None to skip it)."""
+    directory, pass csv_path=None to skip it).  records: detection records of the same
+    frustums - the lines are then formatted from them and the per-box lists are not used."""
     import csv
     import os
     if result_dir is None:
         return
-    results = detection_lines(id_list, type_list, box2d_list, center_list, heading_cls_list, heading_res_list,
-                              size_cls_list, size_res_list, rot_angle_list, score_list)
+    if records is not None:
+        results = detection_lines_from_records(id_list, type_list, box2d_list, records)
+    else:
+        results = detection_lines(id_list, type_list, box2d_list, center_list, heading_cls_list, heading_res_list,
+                                  size_cls_list, size_res_list, rot_angle_list, score_list)
     output_dir = os.path.join(result_dir, "data")
     os.makedirs(output_dir, exist_ok=True)
     for idx, lines in results.items():
@@ -123,6 +202,26 @@ def make_test_iterator(path, batch_size, lenient=True):
             yield flush()
 
 
+def inference_records(feed_dict, model, batch_size):
+    """The device form of `inference`: batch by batch through `model.detect` (network +
+    fpn_detection_records) -> (records (total,20) float64, seg (total,N) int64) host arrays.
+    feed_dict may carry "rot_angle" (total,) for the label fields; without it they are
+    those of unrotated frustums.  Rows beyond the last complete batch stay zero, like the
+    reference's buffers."""
+    pc = np.asarray(feed_dict["frustum_point_cloud"])
+    oh = np.asarray(feed_dict["one_hot_vec"])
+    total = pc.shape[0]
+    records = np.zeros((total, RECORD))
+    seg = np.zeros((total, pc.shape[1]), np.int64)
+    rot = feed_dict.get("rot_angle")
+    for i in range(int(total / batch_size)):
+        sl = slice(i * batch_size, (i + 1) * batch_size)
+        rec, bits = model.detect(pc[sl], oh[sl], None if rot is None else np.asarray(rot)[sl], want_seg=True)
+        records[sl] = rec.cpu().numpy()
+        seg[sl] = unpack_seg_bits(bits, pc.shape[1])
+    return records, seg
+
+
 def inference(feed_dict, model, batch_size):
     """scripts/test.py:122-162: run `model.predict` batch by batch and post-process.
     The reference hands the WHOLE feed_dict to predict in every iteration (:135), which
@@ -133,6 +232,9 @@ def inference(feed_dict, model, batch_size):
     oh = np.asarray(feed_dict["one_hot_vec"])
     total = pc.shape[0]
     num_batches = int(total / batch_size)
+    if hasattr(model, "detect"):
+        records, seg = inference_records(feed_dict, model, batch_size)
+        return (seg,) + outputs_from_records(records)[1:]
     logits = np.zeros((total, pc.shape[1], NUM_CLASSES))
     centers = np.zeros((total, 3))
     from .model_util import NUM_HEADING_BIN, NUM_SIZE_CLUSTER
@@ -167,11 +269,18 @@ def test(model, test_loader, output_filename, result_dir=None, idx_path=None, ba
     names = ("ps", "segp", "center", "heading_cls", "heading_res", "size_cls", "size_res", "rot_angle", "score",
              "onehot", "class", "token", "box2d")
     lists = {k: [] for k in names}
+    all_records = []
     for data_dict in test_loader:
         pc = data_dict["frustum_point_cloud"]
         bs = batch_size or pc.shape[0]
-        seg, centers, hcls, hres, scls, sres, scores = inference(
-            {"frustum_point_cloud": pc, "one_hot_vec": data_dict["one_hot_vec"]}, model, bs)
+        if hasattr(model, "detect"):
+            rec, seg = inference_records({"frustum_point_cloud": pc, "one_hot_vec": data_dict["one_hot_vec"],
+                                          "rot_angle": data_dict["rot_angle"]}, model, bs)
+            all_records.append(rec if pc.shape[0] % bs == 0 else None)
+            _, centers, hcls, hres, scls, sres, scores = outputs_from_records(rec)
+        else:
+            seg, centers, hcls, hres, scls, sres, scores = inference(
+                {"frustum_point_cloud": pc, "one_hot_vec": data_dict["one_hot_vec"]}, model, bs)
         for i in range(pc.shape[0]):
             lists["ps"].append(pc[i, ...])
             lists["segp"].append(seg[i, ...])
@@ -195,7 +304,9 @@ def test(model, test_loader, output_filename, result_dir=None, idx_path=None, ba
         write_detection_results(result_dir, token_ids, [int(c) for c in lists["class"]], lists["box2d"],
                                 [np.array(c) for c in lists["center"]],
                                 lists["heading_cls"], lists["heading_res"], lists["size_cls"], lists["size_res"],
-                                lists["rot_angle"], lists["score"], csv_path=csv_path)
+                                lists["rot_angle"], lists["score"], csv_path=csv_path,
+                                records=np.concatenate(all_records)
+                                if all_records and all(r is not None for r in all_records) else None)
         if idx_path is not None:
             with open(idx_path) as f:
                 fill_files(os.path.join(result_dir, "data"), [line.rstrip() + ".txt" for line in f])

@@ -43,6 +43,22 @@ class DetectionModel:
         oh = torch.as_tensor(np.ascontiguousarray(oh, dtype=np.float32)).to(self.device)
         return [t.cpu().numpy() for t in self(pc, oh)]
 
+    def detect(self, point_cloud, one_hot_vec, rot_angle=None, want_seg=False):
+        """Network + detection-record kernel, nothing but the records leaves the device:
+        inputs as numpy arrays or device tensors, rot_angle (B,) or None ->
+        (records (B,20) float64, seg_bits (B,ceil(N/32)) int32 or None) device tensors
+        (fpn.inference.detection_records; scripts/test.py:145-160 + provider.py:366-373)."""
+        from .. import inference
+
+        def dev(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(self.device, torch.float32).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        ep = self._forward(dev(point_cloud), dev(one_hot_vec))
+        rot = None if rot_angle is None else dev(rot_angle).reshape(-1)
+        return inference.detection_records(ep["mask_logits"].contiguous(), ep["box_output"].contiguous(),
+                                           ep["stage1_center"].contiguous(), rot, want_seg=want_seg)
+
     def load_weights(self, mapping):
         """mapping: variable name -> array (see fpn.variables for the names)."""
         self.store.load(mapping)

@@ -46,6 +46,86 @@ def algorithmic_macs_per_frustum(n, m=512, pc_channels=4):
     return seg_pt * n + seg_fr + tnet + box
 
 
+def reference_macs_per_frustum_v1(n, m=512, pc_channels=4):
+    """MACs of the v1 graph as the reference multiplies it: conv6 over the tiled 1091-wide
+    tensor of every point (frustum_pointnets_v1.py:64-70); 1026.4 M at n=1024, 4 channels."""
+    return algorithmic_macs_per_frustum(n, m, pc_channels) - 1027 * 512 + 1027 * 512 * n
+
+
+def v2_macs_per_frustum(cfg, n, m=512, pc_channels=4):
+    """MACs of one frustum through the v2 graph -> (as the reference's modules multiply it,
+    as executed here).  Reference form: every gathered row goes through the whole first
+    layer (pointnet_util.py:116-121, :177-190) and every dense point through the whole first
+    feature-propagation layer on the concatenated tensor (:218-226).  Executed form: the
+    features' rows of a first layer meet each POINT once where the features are >= 32 wide
+    (the gathered rows add only the 3 coordinate channels), the interpolated features'
+    rows of a feature-propagation layer meet each KNOWN point once, and a single known point
+    (group-all level) enters as one row per frustum.  Zero padding of narrow layers to the
+    kernels' tile widths is not counted in either."""
+    def stack(cin, widths):
+        total = 0
+        for w in widths:
+            total += cin * w
+            cin = w
+        return total
+    cf0 = pc_channels - 3
+    seg, box = cfg["seg"], cfg["box"]
+    ref = exe = 0
+    # --- segmentation net
+    np1 = seg["sa1"]["npoint"]
+    c1 = 0
+    for ns, mlp in zip(seg["sa1"]["nsample"], seg["sa1"]["mlp"]):
+        rows = np1 * ns
+        ref += rows * stack(cf0 + 3, mlp)
+        exe += rows * stack(cf0 + 3, mlp) if cf0 < 32 else n * cf0 * mlp[0] + rows * (3 * mlp[0] + stack(mlp[0], mlp[1:]))
+        c1 += mlp[-1]
+    np2 = seg["sa2"]["npoint"]
+    c2 = 0
+    for ns, mlp in zip(seg["sa2"]["nsample"], seg["sa2"]["mlp"]):
+        rows = np2 * ns
+        ref += rows * stack(c1 + 3, mlp)
+        exe += np1 * c1 * mlp[0] + rows * (3 * mlp[0] + stack(mlp[0], mlp[1:]))
+        c2 += mlp[-1]
+    g = np2 * stack(c2 + 3, seg["sa3"]["mlp"])
+    ref += g; exe += g
+    c3 = seg["sa3"]["mlp"][-1] + 3                       # + one-hot
+    f1, f2, f3 = seg["fp1"], seg["fp2"], seg["fp3"]
+    ref += np2 * stack(c3 + c2, f1)
+    exe += c3 * f1[0] + np2 * (c2 * f1[0] + stack(f1[0], f1[1:]))
+    ref += np1 * stack(f1[-1] + c1, f2)
+    exe += np2 * f1[-1] * f2[0] + np1 * (c1 * f2[0] + stack(f2[0], f2[1:]))
+    head = stack(f3[-1], [128, 2])
+    ref += n * (stack(f2[-1] + pc_channels, f3) + head)
+    exe += np1 * f2[-1] * f3[0] + n * (pc_channels * f3[0] + stack(f3[0], f3[1:]) + head)
+    # --- T-Net (the v1 one)
+    t = (3 * 128 + 128 * 128 + 128 * 256) * m + 259 * 256 + 256 * 128 + 128 * 3
+    ref += t; exe += t
+    # --- box net
+    b1, b2 = box["sa1"], box["sa2"]
+    r1 = b1["npoint"] * b1["nsample"]
+    ref += r1 * stack(3, b1["mlp"]); exe += r1 * stack(3, b1["mlp"])
+    r2 = b2["npoint"] * b2["nsample"]
+    ref += r2 * stack(b1["mlp"][-1] + 3, b2["mlp"])
+    exe += b1["npoint"] * b1["mlp"][-1] * b2["mlp"][0] + r2 * (3 * b2["mlp"][0] + stack(b2["mlp"][0], b2["mlp"][1:]))
+    g = b2["npoint"] * stack(b2["mlp"][-1] + 3, box["sa3"]["mlp"])
+    ref += g; exe += g
+    fc = stack(box["sa3"]["mlp"][-1] + 3, [512, 256, 59])
+    ref += fc; exe += fc
+    return ref, exe
+
+
+def bayes_macs_per_frustum(n, samples, m=512):
+    """MACs of one frustum's S-sample Flipout ensemble (3-channel v1 topology without batch
+    norm, FPointNet_Bayes.py:54-136) -> (textbook form, as executed).  Textbook: every Flipout
+    layer is two products per sample (mean and perturbation) over the graph as the reference
+    multiplies it; the two output layers are plain.  Executed: all points of a frustum share
+    their signs, so a layer is ONE product with the frustum's effective weights, and the
+    frustum-constant inputs of conv6 are applied once per (sample, frustum)."""
+    ref1 = reference_macs_per_frustum_v1(n, m, 3)
+    plain = 128 * 3 + 256 * 59
+    return samples * (2 * (ref1 - plain) + plain), samples * algorithmic_macs_per_frustum(n, m, 3)
+
+
 # ---- launching --------------------------------------------------------------------
 
 def spawn_ranks(gpus):
@@ -82,6 +162,26 @@ def init_rank(local_rank, world):
         else:
             dist.init_process_group("nccl", device_id=dev)
     return dev
+
+
+def rank_identity(rank, dev, world):
+    """What this rank ran on, for the record: device name, PCI bus id, compute units, the
+    collective backend and its library version - gathered from every rank so that an N-GPU
+    line shows N distinct devices behind one RCCL job."""
+    props = torch.cuda.get_device_properties(dev)
+    info = {"rank": rank, "device_index": dev.index, "name": props.name,
+            "gcn_arch": getattr(props, "gcnArchName", None), "compute_units": props.multi_processor_count,
+            "hbm_gib": round(props.total_memory / 2 ** 30, 1),
+            "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                                getattr(props, "pci_device_id", 0)),
+            "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(), "host": socket.gethostname(),
+            "backend": dist.get_backend() if world > 1 else None}
+    if world > 1 and not REHEARSAL:
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:       # the version query is evidence only; its absence must not end the run
+            info["rccl_version"] = "unavailable: %s" % e
+    return info
 
 
 # ---- timing ------------------------------------------------------------------------
@@ -401,17 +501,29 @@ def build_v1(args, dev, rank, world):
     pc_np, oh_np = synthetic.make_frustums_range(lo, hi, points, 4, seed=0)
     pc, one_hot = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
     macs = algorithmic_macs_per_frustum(points)
+    rot = synthetic_rot_angles(lo, hi, dev)
     return {
-        "step": lambda: fdist.pack_results(net.forward(pc, one_hot)),
-        "gather": "records", "frustums": b_local, "points": points, "cpu": "v1",
+        "step": (lambda: fdist.pack_results(net.forward(pc, one_hot))) if args.records == "raw"
+        else (lambda: fdist.pack_detections(net.forward(pc, one_hot), rot)),
+        "gather": "records" if args.records == "raw" else "detections", "frustums": b_local, "points": points,
+        "cpu": "v1",
         "metric": "frustums/sec (node) FPointNet v1 N=%d" % points,
         "label": "Frustum PointNet v1 inference, %d frustums x %d pts x 4 ch per GPU, %s"
                  % (b_local, points, "bf16 MFMA with fp32 accumulation (not the headline configuration, which is "
                     "fp32)" if bf16 else "fp32 MFMA (BASELINE config 1)"),
         "workload_tag": "v1_%s_%dx%d" % (args.dtype, b_local, points) if not args.chunk else None,
-        "extra_config": {"algorithmic_gflop_per_frustum": 2 * macs / 1e9},
+        "extra_config": {"algorithmic_gflop_per_frustum": 2 * macs / 1e9,
+                         "reference_graph_gflop_per_frustum": 2 * reference_macs_per_frustum_v1(points) / 1e9},
         "model_flops_per_frustum": 2.0 * macs,
     }
+
+
+def synthetic_rot_angles(lo, hi, dev):
+    """Frustum angles of frustums lo..hi-1 of the global set (one seeded stream for the set,
+    like the points): what the label fields of a detection record are rotated back by."""
+    import numpy as np
+    rot = np.random.RandomState(11).uniform(-np.pi, np.pi, hi).astype(np.float32)[lo:hi]
+    return torch.from_numpy(np.ascontiguousarray(rot)).to(dev)
 
 
 def build_v2(args, dev, rank, world):
@@ -435,14 +547,17 @@ def build_v2(args, dev, rank, world):
     def forward(pc_, oh_):
         with variables.use_store(st):
             return M2.get_model(pc_, oh_, False)
-    step = lambda: fdist.pack_results(forward(pc, one_hot))       # noqa: E731
+    raw = args.records == "raw"
+    rot = synthetic_rot_angles(lo, hi, dev)
+    pack = fdist.pack_results if raw else (lambda ep: fdist.pack_detections(ep, rot))      # noqa: E731
+    step = lambda: pack(forward(pc, one_hot))       # noqa: E731
     label = "Frustum PointNet v2 (SA-MSG x2, SA, FP x3; box net SA x3) inference, %d frustums x %d pts x 4 ch " \
             "per GPU, %s" % (b_local, points, "bf16 MFMA in the set-abstraction kernels, fp32 elsewhere"
                              if args.dtype == "bf16" else "fp32")
     per_step = b_local
     if args.graph:
         from fpn.graph import GraphedForward
-        graphed = GraphedForward(lambda p, o: fdist.pack_results(forward(p, o)), [pc, one_hot])
+        graphed = GraphedForward(lambda p, o: pack(forward(p, o)), [pc, one_hot])
         step = lambda: graphed(pc, one_hot)       # noqa: E731
         label += ", HIP-graph replay"
     if args.stream_total:
@@ -452,14 +567,20 @@ def build_v2(args, dev, rank, world):
         host_pc = pc.cpu().repeat(reps, 1, 1)[:args.stream_total].contiguous().pin_memory()
         host_oh = one_hot.cpu().repeat(reps, 1)[:args.stream_total].contiguous().pin_memory()
         per_step = args.stream_total
-        step = lambda: fdist.run_streamed(forward, host_pc, host_oh, b_local, dev)       # noqa: E731
+        host_rot = None if raw else rot.cpu().repeat(reps)[:args.stream_total].contiguous()
+        step = lambda: fdist.run_streamed(forward, host_pc, host_oh, b_local, dev, detections=not raw,       # noqa: E731
+                                          rot_angle=host_rot)
         label += ", %d frustums per GPU streamed from pinned host memory in chunks of %d (host-to-device copies " \
                  "inside the timed region, overlapped with compute)" % (args.stream_total, b_local)
     plain = not (args.graph or args.stream_total)
-    return {"step": step, "gather": "records", "frustums": per_step, "points": points, "cpu": "v2",
+    ref_macs, exe_macs = v2_macs_per_frustum(M2.CONFIG, points)
+    return {"step": step, "gather": "records" if raw else "detections", "frustums": per_step, "points": points,
+            "cpu": "v2",
             "metric": "frustums/sec (node) FPointNet v2 N=%d" % points, "label": label,
             "workload_tag": "v2_%s_%dx%d" % (args.dtype, b_local, points) if plain else None,
-            "extra_config": {}, "model_flops_per_frustum": None, "params": st.numpy}
+            "extra_config": {"algorithmic_gflop_per_frustum": 2 * exe_macs / 1e9,
+                             "reference_graph_gflop_per_frustum": 2 * ref_macs / 1e9},
+            "model_flops_per_frustum": 2.0 * exe_macs, "params": st.numpy}
 
 
 def build_bayes(args, dev, rank, world):
@@ -488,7 +609,11 @@ def build_bayes(args, dev, rank, world):
     return {"step": step, "gather": "statistics", "frustums": b_local, "points": points, "cpu": "bayes",
             "metric": "frustums/sec (node) FPointNet Bayes S=%d N=%d" % (args.samples, points), "label": label,
             "workload_tag": "bayes_%s_S%d_%dx%d" % (args.dtype, args.samples, b_local, points),
-            "extra_config": {"samples": args.samples}, "model_flops_per_frustum": None}
+            "extra_config": {"samples": args.samples,
+                             "algorithmic_gflop_per_frustum": 2 * bayes_macs_per_frustum(points, args.samples)[1] / 1e9,
+                             "reference_graph_gflop_per_frustum":
+                                 2 * bayes_macs_per_frustum(points, args.samples)[0] / 1e9},
+            "model_flops_per_frustum": 2.0 * bayes_macs_per_frustum(points, args.samples)[1]}
 
 
 # ---- main ---------------------------------------------------------------------------------
@@ -516,6 +641,8 @@ def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
             # fence at the end of the timed region waits for every stream); gloo: synchronous
             if wl["gather"] == "statistics":
                 res = fdist.gather_statistics(rec, out=gathered[0], async_op=not REHEARSAL)
+            elif wl["gather"] == "detections":
+                res = fdist.gather_detections(rec, out=gathered[0], async_op=not REHEARSAL)
             else:
                 res = fdist.gather_results(rec, out=gathered[0], async_op=not REHEARSAL)
             last_work[0] = None if REHEARSAL else res[1]
@@ -578,22 +705,34 @@ def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    ident = rank_identity(rank, dev, world)
+    ranks = [ident]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, ident)
+
     value = world * wl["frustums"] * args.steps / dt
     config = {"workload": wl["label"], "frustums_per_gpu": wl["frustums"], "points": wl["points"],
               "data": "shards of one global seeded batch (fpn.synthetic.make_frustums_range, seed 0)",
               "parallelism": "frustum-sharded x%d, one all_gather of %s" % (
-                  world, "%d-float ensemble statistics" % fdist.STATS if wl["gather"] == "statistics"
-                  else "%d-float result records" % fdist.RECORD)}
+                  world, {"statistics": "%d-float ensemble statistics" % fdist.STATS,
+                          "detections": "%d-double detection records (label fields, score, class picks; the record "
+                                        "kernel runs inside the timed step)" % fdist.DETECTION,
+                          "records": "%d-float result records" % fdist.RECORD}[wl["gather"]])}
     config.update(wl["extra_config"])
     config["workload_tag"] = wl["workload_tag"]
     if wl["model_flops_per_frustum"]:
+        # (a bf16 step is priced against the bf16 peak although its first layers, fully connected layers and
+        # point-set operators run in fp32: a lower bound of the fraction)
         peak_model = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         config["model_tflops"] = value * wl["model_flops_per_frustum"] / 1e12
         config["model_frac_of_mfma_peak"] = config["model_tflops"] / (peak_model * world)
+        config["model_peak_tflops_per_gpu"] = peak_model
     out = {"metric": wl["metric"], "value": value, "unit": "frustums/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "settle_steps": settle_steps(args.warmup), "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-           "data": "synthetic", "config": config}
+           "data": "synthetic", "config": config, "ranks": ranks,
+           "distinct_devices": len({(r["host"], r["pci_bus_id"], r["uuid"]) for r in ranks})}
     if rank == 0:
         if timer is not None:
             agg = timer.summary()
@@ -625,14 +764,14 @@ def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
                                   "ms_fastest_step": v[3] * 1e3,
                                   "tflops": v[1] / v[2] / 1e12 if v[2] > 0 else None} for k, v in full.items()}
             out["kernels_source"] = "3 steps after the timed region, HIP events around every fused launch"
-        if extras and world == 1 and not args.no_pointset and args.config in ("v1", "v2"):
+        if extras and not args.no_pointset and args.config in ("v1", "v2"):
             # 256 frustums = one workgroup per CU for the per-frustum kernels (FPS, ball
             # query): latency-bound; 4096 frustums lets several workgroups share a CU
             out["pointset_ops"] = pointset_ops(dev)
             out["pointset_ops_4096_frustums"] = pointset_ops(dev, frustums=4096, reps=5)
             if not args.no_cpu_baseline:
                 out["pointset_cpu"] = pointset_cpu()
-        if extras and not args.no_cpu_baseline and world == 1:
+        if extras and not args.no_cpu_baseline:       # rank 0, any world size: host timing needs no GPU
             out["cpu_baseline"] = cpu_baseline(wl["cpu"], seconds=cpu_seconds, samples=args.samples,
                                                params=wl["params"]() if "params" in wl else None)
     return out
@@ -666,6 +805,10 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="operand type of the layer-chain kernels' matrix products (accumulation is always fp32); "
                          "f32 is the headline configuration")
+    ap.add_argument("--records", choices=("detections", "raw"), default="detections",
+                    help="what a step ends with and the all-gather carries: detections = the 20-double detection "
+                         "records of fpn_detection_records (label fields, score, picks; default), raw = the 65-float "
+                         "box vector + centres (no score without the logits)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a HIP graph (--config v2; removes the host launch overhead)")
     args = ap.parse_args()

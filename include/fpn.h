@@ -658,6 +658,36 @@ int fpn_box3d_best_overlap_f64(int npred, const double *pred, const double *gt,
 int fpn_mc_statistics(int s, int b, const float *box_output, const float *stage1_center,
                       float *stats, void *stream);
 
+/*
+ * Detection records: the host arithmetic that follows `model.predict` in the reference's
+ * detection driver (scripts/test.py:145-160: soft-max scores, arg-max classes, residual
+ * picks) and in its label writer (scripts/provider.py:366-373 from_prediction_to_label_format
+ * = class2size :101-104, class2angle :73-82, rotate_pc_along_y :35-48, ty += h/2), as one
+ * kernel over the network's outputs.
+ *   mask_logits (b,n,2) f32, box_output (b,59) f32 (the box net's raw vector, sliced as
+ *   models/model_util.py:211-243), stage1_center (b,3) f32, rot_angle (b) f32 or NULL (= 0:
+ *   frustums that were not rotated to the centre view).
+ *   records (b, FPN_DETECTION_RECORD) f64:
+ *     [0:7]   h, w, l, tx, ty, tz, ry  - the label fields, float64 arithmetic on the fp32
+ *             outputs as the reference's numpy code performs it; angle > pi wraps by -2pi
+ *             before rot_angle is added; cos/sin of the fp32 angle are fp32 (correctly
+ *             rounded here)
+ *     [7]     score = (mean soft-max probability of the positive points + max heading
+ *             probability + max size probability) / 3, soft-max in fp32, the mean in
+ *             float64; NaN for a frustum without positive points (test.py:148 divides 0/0)
+ *     [8],[9] heading_cls, size_cls (first maximum, as np.argmax)
+ *     [10]    heading_res, [11:14] size_res (l,w,h)  (fp32 products of the model graph)
+ *     [14:17] center = center_boxnet + stage1_center (frustum frame, fp32 sum)
+ *     [17]    number of positive points, [18] max heading probability, [19] max size probability
+ *   seg_bits (b, ceil(n/32)) u32 or NULL: bit (j mod 32) of word j/32 = 1 iff point j is an
+ *   object point (np.argmax(logits, 2), test.py:162: logit 1 strictly above logit 0).
+ * One wave per frustum; reads every input once.
+ */
+#define FPN_DETECTION_RECORD 20
+int fpn_detection_records(int b, int n, const float *mask_logits, const float *box_output,
+                          const float *stage1_center, const float *rot_angle, double *records,
+                          unsigned *seg_bits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

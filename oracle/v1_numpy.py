@@ -233,3 +233,43 @@ def inference_postprocess(logits, centers, heading_scores, heading_residuals,
     heading_res = np.array([heading_residuals[i, heading_cls[i]] for i in range(n)])
     size_res = np.vstack([size_residuals[i, size_cls[i], :] for i in range(n)])
     return np.argmax(logits, 2), centers, heading_cls, heading_res, size_cls, size_res, scores
+
+
+# mean sizes (l,w,h) by size-cluster index, scripts/provider.py:25-33 (= models/model_util.py:38-48)
+_MEAN_SIZE = np.array([[3.88311640418, 1.62856739989, 1.52563191462], [5.06763659, 1.9007158, 2.20532825],
+                       [10.13586957, 2.58549199, 3.2520595], [0.84422524, 0.66068622, 1.76255119],
+                       [0.80057803, 0.5983815, 1.27450867], [1.76282397, 0.59706367, 1.73698127],
+                       [16.17150617, 2.53246914, 3.53079012], [3.64300781, 1.54298177, 1.92320313]])
+
+
+def label_fields(centers, heading_cls, heading_res, size_cls, size_res, rot_angle, trig="exact"):
+    """The label conversion of scripts/provider.py:366-373 for a batch, written out
+    element by element in float64 (no shared code with the product's fpn/provider.py):
+      l,w,h = mean_size[size_cls] + size_res                                 (:101-104)
+      angle = heading_cls * (2 pi / 12) + heading_res; angle > pi: -2 pi     (:73-82)
+      ry    = angle + rot_angle                                              (:370)
+      tx,tz = the centre's x,z rotated about y by -rot_angle                 (:35-48, :371)
+      ty    = centre y + h/2                                                 (:372)
+    -> (B,7) columns h,w,l,tx,ty,tz,ry.
+    rot_angle is a float32 array (the record files hold float32): the reference evaluates
+    np.cos / np.sin on the float32 scalar and gets float32 numbers.  trig="exact": the
+    correctly rounded float32 cosine and sine (float64 evaluation rounded once);
+    trig="numpy": numpy's own float32 routines (within an ulp or two of the former)."""
+    centers = np.asarray(centers, np.float64)
+    size = _MEAN_SIZE[np.asarray(size_cls)] + np.asarray(size_res, np.float64)
+    angle = np.asarray(heading_cls).astype(np.float64) * (2 * np.pi / 12.0) + np.asarray(heading_res, np.float64)
+    angle = np.where(angle > np.pi, angle - 2 * np.pi, angle)
+    rot = np.asarray(rot_angle, np.float32)
+    neg = -rot
+    if trig == "exact":
+        c = np.cos(neg.astype(np.float64)).astype(np.float32).astype(np.float64)
+        s = np.sin(neg.astype(np.float64)).astype(np.float32).astype(np.float64)
+    else:
+        c = np.cos(neg).astype(np.float64)
+        s = np.sin(neg).astype(np.float64)
+    x, y, z = centers[:, 0], centers[:, 1], centers[:, 2]
+    # row vector [x z] times transpose([[c,-s],[s,c]]) = [x*c + z*(-s), x*s + z*c]
+    tx = x * c + z * (-s)
+    tz = x * s + z * c
+    h = size[:, 2]
+    return np.stack([h, size[:, 1], size[:, 0], tx, y + h / 2.0, tz, angle + rot.astype(np.float64)], axis=1)

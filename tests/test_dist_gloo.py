@@ -2,6 +2,7 @@
 build per-frustum result records, and all-gather them (the same fpn.dist code the
 benchmark runs over RCCL with one rank per GPU)."""
 import os
+import socket
 import sys
 
 import numpy as np
@@ -10,6 +11,13 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    """A port nobody listens on right now (two suites on one host do not collide)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def _worker(rank, world, port, total, out_dir):
@@ -51,7 +59,17 @@ def _worker(rank, world, port, total, out_dir):
     full_s = fdist.gather_statistics(stats, total)
     if total % world == 0:
         assert torch.equal(fdist.gather_statistics(stats), full_s)
-    torch.save({"full": full, "full_l": full_l, "full_s": full_s}, os.path.join(out_dir, "rank%d.pt" % rank))
+    # finished detections: float64 records (the kernel that fills them needs a GPU; the
+    # gather is dtype-agnostic)
+    det = ids[:, None].double() * 3 + torch.arange(fdist.DETECTION, dtype=torch.float64)[None] / 7.0
+    full_d = fdist.gather_detections(det, total)
+    if total % world == 0:
+        assert torch.equal(fdist.gather_detections(det), full_d)
+        out_d, w4 = fdist.gather_detections(det, async_op=True)
+        w4.wait()
+        assert torch.equal(out_d, full_d)
+    torch.save({"full": full, "full_l": full_l, "full_s": full_s, "full_d": full_d},
+               os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,15 +89,18 @@ def _run(total, tmp_path, port):
         assert lg.shape == (total, 4, 2) and torch.equal(lg[:, 0, 0], torch.arange(total, dtype=torch.float32))
         want_s = torch.arange(total, dtype=torch.float32)[:, None] * 2 + torch.arange(fdist.STATS)[None] / 10.0
         assert torch.equal(o["full_s"], want_s)
+        want_d = torch.arange(total, dtype=torch.float64)[:, None] * 3 + \
+            torch.arange(fdist.DETECTION, dtype=torch.float64)[None] / 7.0
+        assert o["full_d"].dtype == torch.float64 and torch.equal(o["full_d"], want_d)
     assert torch.equal(outs[0]["full"], outs[1]["full"])
 
 
 def test_two_rank_gather_even(tmp_path):
-    _run(10, tmp_path, 29511)
+    _run(10, tmp_path, _free_port())
 
 
 def test_two_rank_gather_ragged(tmp_path):
-    _run(7, tmp_path, 29512)
+    _run(7, tmp_path, _free_port())
 
 
 def _toy_forward(pc, oh):
@@ -111,7 +132,7 @@ def test_two_rank_streamed_scene_set(tmp_path):
     """Scene set of 11 frustums, 2 ranks, chunks of 3: every rank streams its block and all
     ranks end with the records of the whole set in frustum order."""
     total, chunk = 11, 3
-    mp.spawn(_stream_worker, args=(2, 29513, total, chunk, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_stream_worker, args=(2, _free_port(), total, chunk, str(tmp_path)), nprocs=2, join=True)
     from fpn import dist as fdist
     rng = np.random.RandomState(0)
     pc = torch.from_numpy(rng.standard_normal((total, 8, 4)).astype(np.float32))
