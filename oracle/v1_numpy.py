@@ -62,6 +62,14 @@ def dense(x, params, scope, bn, relu, dtype):
     return y
 
 
+def summed_magnitude(x, params, scope):
+    """sum_k |x_k| |w_kj| + |b_j| for a layer without batch norm: the magnitude of what the
+    layer's output sums.  The rounding error of a sum is judged against it (with random
+    weights the sum itself can be a hundredth of it), tests of the bf16 path scale by it."""
+    w = np.abs(params[scope + "/weights"].astype(np.float64))
+    return np.abs(np.asarray(x, np.float64)) @ w.reshape(-1, w.shape[-1]) + np.abs(params[scope + "/biases"].astype(np.float64))
+
+
 def instance_seg_v1(point_cloud, one_hot, params, bn=True, dtype=np.float32):
     """get_instance_seg_v1_net, models/frustum_pointnets_v1.py:20-90."""
     B, N, _ = point_cloud.shape
@@ -133,8 +141,9 @@ def point_cloud_masking(point_cloud, logits, policy="first", rng=None, dtype=np.
     return obj, mean, mask, idx
 
 
-def center_regression_net(obj_pc, one_hot, params, bn=True, dtype=np.float32):
-    """get_center_regression_net (T-Net), models/model_util.py:322-357."""
+def center_regression_net(obj_pc, one_hot, params, bn=True, dtype=np.float32, magnitude=None):
+    """get_center_regression_net (T-Net), models/model_util.py:322-357.
+    magnitude: a dict that receives summed_magnitude of the output layer under 'center_delta'."""
     net = obj_pc
     for scope, _ in TNET_CONV:                        # :335-346
         net = dense(net, params, scope, bn, True, dtype)
@@ -142,6 +151,8 @@ def center_regression_net(obj_pc, one_hot, params, bn=True, dtype=np.float32):
     net = np.concatenate([net, one_hot.astype(dtype)], axis=1)        # :350
     for scope, _ in TNET_FC:                          # :351-354
         net = dense(net, params, scope, bn, True, dtype)
+    if magnitude is not None:
+        magnitude["center_delta"] = summed_magnitude(net, params, "fc3-stage1")
     return dense(net, params, "fc3-stage1", False, False, dtype)      # :355
 
 

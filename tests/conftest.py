@@ -24,11 +24,13 @@ def device():
 
 @pytest.fixture(autouse=True)
 def _seeded_global_generators():
-    """Every test starts from the same state of the process-wide generators (torch's default
-    CPU/GPU generators, numpy's legacy one): a test that draws from them without a generator
-    of its own gives the same numbers in every run and in any selection of tests."""
+    """No test's verdict depends on the process-wide generators (torch's default CPU/GPU
+    generators, numpy's legacy one): every test draws from generators it seeds itself.  They
+    are still put into a known state before each test so that a run is reproducible; the
+    state comes from FPN_TEST_SEED, and the suite passes for any value of it."""
     import numpy as np
     import torch
-    torch.manual_seed(20240611)
-    np.random.seed(20240611)
+    seed = int(os.environ.get("FPN_TEST_SEED", "20240611"))
+    torch.manual_seed(seed)
+    np.random.seed(seed % (1 << 32))
     yield

@@ -17,6 +17,17 @@ from oracle import v1_numpy as V
 pytestmark = pytest.mark.gpu
 
 
+def _bias_generator(st, _made={}):
+    """One CPU generator per variable store, seeded by a constant: the bias draws of a test do
+    not depend on the process-wide generator or on which tests ran before."""
+    g = _made.get(id(st))
+    if g is None:
+        _made.clear()
+        g = _made[id(st)] = torch.Generator()
+        g.manual_seed(424242)
+    return g
+
+
 def dev(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
@@ -61,7 +72,7 @@ def bayes_setup(device, B=4, N=256, seed=0, chain=True):
     assert bp.chain == chain
     for k in list(st.keys()):
         if k.endswith("/biases"):
-            st[k] = torch.randn(st[k].shape) * 0.1
+            st[k] = torch.randn(st[k].shape, generator=_bias_generator(st)) * 0.1
     pc, oh = synthetic.make_frustums(B, N, 3, seed=seed)
     return st, bp, pc, oh
 
@@ -199,7 +210,7 @@ def test_bayes_mc_dropout(device, chain, N):
     bp = bayes.BayesPlan(st, 3, mc_dropout=True, chain=chain)
     for k in list(st.keys()):
         if k.endswith("/biases"):
-            st[k] = torch.randn(st[k].shape) * 0.1
+            st[k] = torch.randn(st[k].shape, generator=_bias_generator(st)) * 0.1
     B, S = 5, 2       # (the per-layer kernel pools groups of 32, 64 or a multiple of 128 rows)
     pc, oh = synthetic.make_frustums(B, N, 3, seed=4)
     g = torch.Generator(device=device)
@@ -255,7 +266,7 @@ def test_bayes_frustum_blocks_and_single_sample(device, precision):
     whole = bayes.BayesPlan(st, 3, precision=precision)
     for k in list(st.keys()):
         if k.endswith("/biases"):
-            st[k] = torch.randn(st[k].shape) * 0.1
+            st[k] = torch.randn(st[k].shape, generator=_bias_generator(st)) * 0.1
     B, N, S = 10, 128, 3
     pc, oh = synthetic.make_frustums(B, N, 3, seed=1)
     g = torch.Generator(device=device)
