@@ -12,6 +12,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "fpn_common.h"
 
@@ -19,6 +20,7 @@ namespace fpn {
 namespace {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sqdist3(float x2, float y2, float z2, float x1, float y1, float z1)
 {
@@ -225,6 +227,196 @@ int launch_fps(int b, int n, int m, const float *inp, int *out, hipStream_t st)
     size_t lds = (size_t)((n * 3 + 3) & ~3) * 4 + (size_t)4 * (THREADS / kWave) * 4;
     hipLaunchKernelGGL((fps_kernel<THREADS, PPT>), dim3(b), dim3(THREADS), lds, st, n, m, inp, out);
     return check_launch("fpn_farthest_point_sample");
+}
+
+// ---------------------------------------------------------------------------
+// FPS for MANY frustums: one WAVE per frustum, no LDS, no barrier.
+//
+// The workgroup kernel above is built for latency (256 threads on one frustum); with
+// thousands of frustums in flight what counts is vector-ALU instructions per (point,
+// iteration) and whether every SIMD always has a wave ready to issue.  Here a lane owns PPL
+// consecutive points - coordinates and running minimum distances in registers for the
+// whole run, PPL = 32 for 2048 points: 128 registers, three waves per SIMD - and the waves
+// of a SIMD belong to different frustums, so one wave's dependent steps (the cross-lane
+// maximum, the picked point's coordinates coming back from memory) are covered by the
+// others' distance updates.  Per point and iteration: the packed subtract / multiply / add
+// chain (4 instructions for the exactly rounded squared distance), one minimum and half a
+// maximum - 5.5 against 8, and a per-iteration overhead (reduction, search) that is spread
+// over 32 points per lane instead of 8.
+//
+// Lowest index among equal maxima (the tie rule of the workgroup kernel): the lane maximum
+// is a maximum of VALUES only, formed over groups of four positions; after the wave maximum
+// (DPP) the first lane L of the ballot holds the lowest-index maximum, and its position is
+// found by the scalar unit on lane L's values alone: the first group whose maximum equals
+// the wave's (one v_readlane per group), then the first of that group's four positions (the
+// group is wave-uniform, so the register is selected through the scalar index mode).
+// Measured on this chip (tools/valu_issue_probe.hip, clocks per wave instruction and SIMD
+// with several waves resident): v_add_f32 / v_mul_f32 2.4, their packed forms 4.4 (two
+// results), v_min / v_max3 / v_cmp of either type 4.2, any scalar ALU instruction 4.4 - and
+// scalar instructions overlap the vector ones of other waves only partly.  The earlier form
+// of the search (one v_cmp per position for the whole wave, four scalar instructions each to
+// collect lane L's bits) cost 34 vector + 128 scalar instructions per iteration; this one
+// costs about 16 + 40.
+// ---------------------------------------------------------------------------
+constexpr int kFpsWaveWaves = 4;      // waves (= frustums) per workgroup, independent of each other
+
+// ZLDS (the 32-point form): x, y and the minima stay in registers (96), the z coordinates live
+// in LDS as the lane's PRIVATE array - vector i of a lane at ((i * 64 + lane) * 16 bytes: a
+// wave's ds_read_b128 touches consecutive 16-byte slots, no bank conflicts; each lane reads
+// only what it wrote itself, so there is no barrier) - which brings the kernel from 138 to
+// under 128 registers: FOUR waves per SIMD instead of three, and 4096 frustums are exactly
+// one resident wave set of the chip (with three, every fourth wave ran alone at the end).
+//
+// The picked point's coordinates never come from memory: position s (wave-uniform) selects
+// the register through the index mode of the scalar unit (what a uniform dynamic index into
+// a register vector compiles to), lane L's value is read with v_readlane, z comes from the
+// wave's LDS array.  (Read back from memory at a wave-uniform address - a scalar load - the
+// waves spent 40 % of their time waiting for it: sixteen frustums per CU are 384 KiB, far
+// more than the scalar cache.)
+template <int N>
+using fvec = float __attribute__((ext_vector_type(N)));
+template <int N>
+using uvec = unsigned __attribute__((ext_vector_type(N)));
+
+//
+// REG = false (the 8-point form, 512 points: eight waves per SIMD, little work per
+// iteration): there the fixed cost of the search and of the register selection outweighs
+// what it saves; the position is collected from one compare per position (lane L's bit of
+// each ballot, on the scalar unit) and the picked point is read back from memory at a
+// wave-uniform address, its latency covered by the other seven waves.
+template <int PPL, bool ZLDS, bool REG>
+__global__ __launch_bounds__(64 * kFpsWaveWaves, ZLDS ? 4 : 1) void fps_wave_kernel(int b, int n, int m,
+                                                                                  const float *__restrict__ inp,
+                                                                                  int *__restrict__ out)
+{
+    static_assert(PPL % 4 == 0 && PPL <= 32, "the position word holds 32 points per lane");
+    __shared__ float4v zlds[ZLDS ? kFpsWaveWaves * (PPL / 4) * 64 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int f = blockIdx.x * kFpsWaveWaves + wave;
+    if (f >= b) return;          // whole waves leave: nothing below synchronises across waves
+    const float *pts = inp + (size_t)f * n * 3;
+    int *o = out + (size_t)f * m;
+    float4v *zwave = zlds + wave * ((PPL / 4) * 64);       // vector i of lane l at zwave[i * 64 + l]
+
+    // Running minimum distances are kept as BIT PATTERNS: a squared distance is >= +0 or NaN,
+    // so unsigned order is float order, a NaN (any sign) or +inf lies above the 1e38 every
+    // minimum starts from, and min / max / == on the patterns give what `d < md ? d : md`,
+    // `>` and `==` give on the floats - without the canonicalising copies the compiler puts
+    // before float minima of loop-carried values.
+    fvec<PPL> px, py;
+    fvec<ZLDS ? 2 : PPL> pz;
+    uvec<PPL> md;
+    const int base = lane * PPL;
+#pragma unroll
+    for (int s4 = 0; s4 < PPL / 4; ++s4) {
+        float z[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = 4 * s4 + e, k = base + s;
+            const bool valid = k < n;
+            const float *src = pts + (size_t)(valid ? k : 0) * 3;
+            px[s] = valid ? src[0] : 0.f;
+            py[s] = valid ? src[1] : 0.f;
+            z[e] = valid ? src[2] : 0.f;
+            if constexpr (!ZLDS) pz[s] = z[e];
+            // slots past the end: distance 0 and an index above every real point - they can tie
+            // only when every real point is at 0 too, and then point 0 (lower index) wins
+            md[s] = valid ? __float_as_uint(1e38f) : 0u;
+        }
+        if constexpr (ZLDS) zwave[s4 * 64 + lane] = float4v{z[0], z[1], z[2], z[3]};
+    }
+    // (left to itself the compiler forwards the stored z values to the loop's reads - each lane
+    // reads what it wrote - and the array is back in registers: the reads go through a pointer
+    // it knows nothing about)
+    typedef __attribute__((address_space(3))) const float4v *LdsVec;
+    typedef __attribute__((address_space(3))) const float *LdsFloat;
+    LdsVec zread = (LdsVec)zwave;
+    asm volatile("" : "+v"(zread) : : "memory");
+
+    // the first pick is point 0: lane 0, position 0
+    float x1 = pts[0], y1 = pts[1], z1 = pts[2];
+    int mine = 0;      // lane (j mod 64) keeps the j-th pick until 64 are stored together
+    for (int j = 1; j < m; ++j) {
+        if constexpr (ZLDS) asm volatile("" : : : "memory");    // (... nor hoisted out of the loop as invariant)
+#pragma unroll
+        for (int s4 = 0; s4 < PPL / 4; ++s4) {
+            float4v zq;
+            if constexpr (ZLDS) zq = zread[s4 * 64 + lane];
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int s = 4 * s4 + 2 * e2;
+                float2v zz;
+                if constexpr (ZLDS) zz = e2 == 0 ? float2v{zq.x, zq.y} : float2v{zq.z, zq.w};
+                else zz = float2v{pz[s], pz[s + 1]};
+                // (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1), left to right, for two points
+                const float2v dx = float2v{px[s], px[s + 1]} - x1, dy = float2v{py[s], py[s + 1]} - y1, dz = zz - z1;
+                float2v d = dx * dx + dy * dy;
+                d = d + dz * dz;
+                md[s] = min(__float_as_uint(d[0]), md[s]);
+                md[s + 1] = min(__float_as_uint(d[1]), md[s + 1]);
+            }
+        }
+        unsigned g[PPL / 4];
+#pragma unroll
+        for (int q = 0; q < PPL / 4; ++q) g[q] = max(max(md[4 * q], md[4 * q + 1]), max(md[4 * q + 2], md[4 * q + 3]));
+        unsigned best = g[0];
+#pragma unroll
+        for (int q = 1; q < PPL / 4; ++q) best = max(best, g[q]);
+        const unsigned wmax = wave_umax(best);
+        const int L = (int)__builtin_ctzll(__ballot(best == wmax));
+        int sp;
+        if constexpr (REG) {
+            int q0 = 0;
+#pragma unroll
+            for (int q = PPL / 4 - 1; q >= 0; --q)
+                if ((unsigned)__builtin_amdgcn_readlane((int)g[q], L) == wmax) q0 = q;
+            sp = 4 * q0;
+#pragma unroll
+            for (int e = 3; e >= 0; --e)
+                if ((unsigned)__builtin_amdgcn_readlane((int)md[4 * q0 + e], L) == wmax) sp = 4 * q0 + e;
+        } else {
+            unsigned where = 0;
+#pragma unroll
+            for (int s = 0; s < PPL; ++s) where |= (unsigned)((__ballot(md[s] == wmax) >> L) & 1ull) << s;
+            sp = (int)__builtin_ctz(where);
+        }
+        const int old = L * PPL + sp;
+        if constexpr (REG) {
+            x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[sp]), L));
+            y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[sp]), L));
+            if constexpr (ZLDS) z1 = ((LdsFloat)zread)[((sp >> 2) * 64 + L) * 4 + (sp & 3)];
+            else z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[sp]), L));
+        } else {
+            x1 = pts[(size_t)old * 3 + 0];
+            y1 = pts[(size_t)old * 3 + 1];
+            z1 = pts[(size_t)old * 3 + 2];
+        }
+        if (lane == (j & 63)) mine = old;
+        if ((j & 63) == 63) o[j - 63 + lane] = mine;
+    }
+    if ((m & 63) != 0 && lane < (m & 63)) o[(m & ~63) + lane] = mine;
+}
+
+template <int PPL>
+int launch_fps_wave(int b, int n, int m, const float *inp, int *out, hipStream_t st)
+{
+    hipLaunchKernelGGL((fps_wave_kernel<PPL, PPL == 32, PPL >= 16>), dim3((b + kFpsWaveWaves - 1) / kFpsWaveWaves),
+                       dim3(64 * kFpsWaveWaves), 0, st, b, n, m, inp, out);
+    return check_launch("fpn_farthest_point_sample");
+}
+
+// Which kernel a call takes: the wave-per-frustum form from kFpsWaveMinBatch frustums on
+// (at least one wave for every SIMD of the chip) for 257..2048 points; FPN_FPS=block /
+// FPN_FPS=wave force one form where it exists (the two are bit-identical: tests use both).
+constexpr int kFpsWaveMinBatch = 1024;
+inline bool fps_use_wave(int b, int n)
+{
+    if (n <= 256 || n > 2048) return false;
+    const char *e = std::getenv("FPN_FPS");
+    if (e && e[0] == 'b') return false;
+    if (e && e[0] == 'w') return true;
+    return b >= kFpsWaveMinBatch;
 }
 
 // ---------------------------------------------------------------------------
@@ -984,6 +1176,11 @@ int fpn_farthest_point_sample(int b, int n, int m, const float *inp, int *out, v
     FPN_REQUIRE(n >= 1, "farthest_point_sample: npoint > 0 needs at least one input point");
     FPN_REQUIRE(inp && out, "farthest_point_sample: null pointer");
     hipStream_t st = as_stream(stream);
+    if (fps_use_wave(b, n)) {
+        if (n <= 512) return launch_fps_wave<8>(b, n, m, inp, out, st);
+        if (n <= 1024) return launch_fps_wave<16>(b, n, m, inp, out, st);
+        return launch_fps_wave<32>(b, n, m, inp, out, st);
+    }
     if (n <= 64) return launch_fps<64, 1>(b, n, m, inp, out, st);
     if (n <= 128) return launch_fps<64, 2>(b, n, m, inp, out, st);
     if (n <= 256) return launch_fps<64, 4>(b, n, m, inp, out, st);

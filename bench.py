@@ -482,6 +482,17 @@ def pointset_ops(dev, frustums=256, reps=20):
         gbs = B * bytes_per_frustum / ms / 1e6
         out[name] = {"ms": ms, "frustums_per_s": B / ms * 1e3, "algorithmic_bytes_per_frustum": bytes_per_frustum,
                      "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS}
+    # FPS is bound by the vector ALU, not by memory (its bytes are read once, its work is
+    # (m-1) * n distance / minimum / maximum updates): the same time against the vector rate.
+    # One update = 10 lane operations (3 subtractions, 3 products, 2 sums - no fused
+    # multiply-add: each is rounded on its own, as the reference's arithmetic - 1 minimum,
+    # 1 maximum); peak = 256 CUs x 128 lanes x 2.4 GHz single operations per second (half the
+    # fused-multiply-add figure the fp32 vector peak of 157.3 TFLOP/s counts).
+    fps = out["farthest_point_sample(2048->128)"]
+    lane_ops = 10.0 * (M - 1) * N
+    fps["algorithmic_lane_ops_per_frustum"] = lane_ops
+    fps["achieved_Tlaneops"] = B * lane_ops / fps["ms"] / 1e9
+    fps["frac_of_valu_peak"] = fps["achieved_Tlaneops"] / (256 * 128 * 2.4e9 / 1e12)
     return out
 
 

@@ -62,6 +62,51 @@ def test_fps_full_size_properties(device):
     np.testing.assert_array_equal(got[sub], O.farthest_point_sample(128, x[sub]))
 
 
+@pytest.mark.parametrize("n,npoint", [(257, 32), (300, 64), (512, 128), (513, 65), (1000, 64), (1024, 128), (1025, 1),
+                                      (2047, 63), (2048, 128), (2048, 192), (700, 700)])
+def test_fps_wave_per_frustum_kernel(device, monkeypatch, n, npoint):
+    """The many-frustum form (one wave per frustum; picks stored 64 at a time, so counts
+    around the multiples of 64; point counts off the lanes' 8 / 16 / 32-point blocks) against
+    the oracle and bit for bit against the workgroup-per-frustum form."""
+    from fpn.tf_ops.tf_sampling import farthest_point_sample
+    x = clouds(7, n, seed=3 * n + npoint, dup=0.1)     # 7 frustums: a last workgroup with one wave
+    xd = dev(x, device)
+    monkeypatch.setenv("FPN_FPS", "wave")
+    wave = farthest_point_sample(npoint, xd).cpu().numpy()
+    monkeypatch.setenv("FPN_FPS", "block")
+    block = farthest_point_sample(npoint, xd).cpu().numpy()
+    np.testing.assert_array_equal(wave, block)
+    np.testing.assert_array_equal(wave, O.farthest_point_sample(npoint, x))
+
+
+def test_fps_wave_kernel_ties_and_default_dispatch(device, monkeypatch):
+    """Exact ties (a lattice, an all-identical cloud, a mirrored lattice, infinities) through
+    the wave form; and a batch large enough to take it by default (1536 frustums of 2048
+    points) equals the workgroup form on all of them and the oracle on a sample."""
+    from fpn.tf_ops.tf_sampling import farthest_point_sample
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(16), indexing="ij"), -1)
+    lattice = g.reshape(1, -1, 3).astype(np.float32)
+    same = np.ones((1, 1024, 3), np.float32) * 0.25
+    far = clouds(1, 600, seed=9)
+    far[0, 100] = np.inf                      # an infinite distance never replaces a minimum
+    far[0, 200, 1] = np.nan
+    monkeypatch.setenv("FPN_FPS", "wave")
+    for x in (lattice, same, np.concatenate([lattice, lattice[:, ::-1]], 1)):
+        got = farthest_point_sample(64, dev(x, device)).cpu().numpy()
+        np.testing.assert_array_equal(got, O.farthest_point_sample(64, x))
+    wave = farthest_point_sample(40, dev(far, device)).cpu().numpy()
+    monkeypatch.setenv("FPN_FPS", "block")
+    np.testing.assert_array_equal(wave, farthest_point_sample(40, dev(far, device)).cpu().numpy())
+    x = clouds(1536, 2048, seed=21, dup=0.1)
+    xd = dev(x, device)
+    block = farthest_point_sample(128, xd).cpu().numpy()
+    monkeypatch.delenv("FPN_FPS")
+    default = farthest_point_sample(128, xd).cpu().numpy()
+    np.testing.assert_array_equal(default, block)
+    sub = [0, 511, 1024, 1535]
+    np.testing.assert_array_equal(default[sub], O.farthest_point_sample(128, x[sub]))
+
+
 def test_gather_point(device):
     from fpn.tf_ops.tf_sampling import gather_point
     x = clouds(5, 777, seed=1)
