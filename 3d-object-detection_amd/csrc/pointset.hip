@@ -967,20 +967,45 @@ __global__ __launch_bounds__(kNnThreads) void three_nn_interpolate_bf16_kernel(
 // (lowest position on ties, like the reference's strict "<" scan) followed by
 // the reference's swap, so the WHOLE output row - not only its first k columns
 // - equals the reference's.
+//
+// KNN = true is knn_point (models/tf_ops/grouping/tf_grouping.py:49-74) as ONE kernel: the
+// row is not read from a (b,m,n) distance matrix but formed in LDS from the coordinates -
+// sum over the c channels, left to right, of the rounded squares of (xyz1 - xyz2), the
+// float32 value of tf.reduce_sum((xyz1 - xyz2)**2, -1) for the three-channel case - the same
+// k swap steps run on it, and only the first k columns leave (:70-71 slices them): neither
+// the matrix nor the two (b,m,n) output arrays exist.
 // ---------------------------------------------------------------------------
+template <bool KNN>
 __global__ __launch_bounds__(kWave) void selection_sort_kernel(int n, int k,
                                                                const float *__restrict__ dist,
                                                                int *__restrict__ outi,
-                                                               float *__restrict__ out)
+                                                               float *__restrict__ out, int m, int c,
+                                                               const float *__restrict__ xyz1,
+                                                               const float *__restrict__ xyz2)
 {
     extern __shared__ float smem[];
     float *v = smem;
     int *ix = reinterpret_cast<int *>(smem + n);
     const int lane = threadIdx.x;
     const size_t row = blockIdx.x;
-    for (int s = lane; s < n; s += kWave) {
-        v[s] = dist[row * n + s];
-        ix[s] = s;
+    if constexpr (KNN) {
+        const float *q = xyz2 + row * c;                       // row = frustum * m + query
+        const float *pts = xyz1 + (row / m) * (size_t)n * c;
+        for (int s = lane; s < n; s += kWave) {
+            float acc = 0.f;
+            for (int ch = 0; ch < c; ++ch) {
+                const float d = pts[(size_t)s * c + ch] - q[ch];
+                const float sq = d * d;
+                acc = ch == 0 ? sq : acc + sq;
+            }
+            v[s] = acc;
+            ix[s] = s;
+        }
+    } else {
+        for (int s = lane; s < n; s += kWave) {
+            v[s] = dist[row * n + s];
+            ix[s] = s;
+        }
     }
     __syncthreads();
     const int steps = min(k, n);
@@ -1021,9 +1046,17 @@ __global__ __launch_bounds__(kWave) void selection_sort_kernel(int n, int k,
         }
         __syncthreads();
     }
-    for (int s = lane; s < n; s += kWave) {
-        out[row * n + s] = v[s];
-        outi[row * n + s] = ix[s];
+    if constexpr (KNN) {
+        // k > n: the remaining columns hold the unsorted tail, as the slice of the reference's arrays would
+        for (int s = lane; s < k; s += kWave) {
+            out[row * k + s] = s < n ? v[s] : 0.f;
+            outi[row * k + s] = s < n ? ix[s] : 0;
+        }
+    } else {
+        for (int s = lane; s < n; s += kWave) {
+            out[row * n + s] = v[s];
+            outi[row * n + s] = ix[s];
+        }
     }
 }
 
@@ -1376,9 +1409,26 @@ int fpn_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, f
     FPN_REQUIRE(dist && outi && out, "select_top_k: null pointer");
     if (n > 16384) return fail(FPN_E_UNSUPPORTED, "select_top_k: n=%d exceeds the 16384-column limit", n);
     FPN_REQUIRE(rows <= INT32_MAX, "select_top_k: too many rows");
-    hipLaunchKernelGGL(selection_sort_kernel, dim3((unsigned)rows), dim3(kWave), (size_t)n * 8,
-                       as_stream(stream), n, k, dist, outi, out);
+    hipLaunchKernelGGL(selection_sort_kernel<false>, dim3((unsigned)rows), dim3(kWave), (size_t)n * 8,
+                       as_stream(stream), n, k, dist, outi, out, m, 0, static_cast<const float *>(nullptr),
+                       static_cast<const float *>(nullptr));
     return check_launch("fpn_select_top_k");
+}
+
+int fpn_knn_point(int b, int n, int c, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                  void *stream)
+{
+    FPN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && c >= 1, "knn_point: bad size (b=%d n=%d m=%d c=%d)", b, n, m, c);
+    FPN_REQUIRE(k > 0, "SelectionSort expects positive k");
+    FPN_REQUIRE(k <= n, "knn_point: k=%d exceeds the %d dataset points", k, n);
+    long rows = (long)b * m;
+    if (rows == 0) return FPN_OK;
+    FPN_REQUIRE(xyz1 && xyz2 && val && idx, "knn_point: null pointer");
+    if (n > 16384) return fail(FPN_E_UNSUPPORTED, "knn_point: n=%d exceeds the 16384-point limit", n);
+    FPN_REQUIRE(rows <= INT32_MAX, "knn_point: too many rows");
+    hipLaunchKernelGGL(selection_sort_kernel<true>, dim3((unsigned)rows), dim3(kWave), (size_t)n * 8, as_stream(stream), n,
+                       k, static_cast<const float *>(nullptr), idx, val, m, c, xyz1, xyz2);
+    return check_launch("fpn_knn_point");
 }
 
 int fpn_mask_gather(int b, int n, int cpc, int npick, int policy, const float *point_cloud, const float *logits,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "fpn_three_nn_interpolate": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fpn_three_nn_interpolate_bf16": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_select_top_k": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "fpn_knn_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fpn_shared_mlp_f32": [_l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
     "fpn_mlp_pack_bf16": [_i, _i, _vp, _vp, _vp],
     "fpn_shared_mlp_bf16": [_l, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],

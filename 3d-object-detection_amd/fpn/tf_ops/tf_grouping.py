@@ -102,14 +102,40 @@ def group_point(points, idx):
     return out
 
 
+# knn_point as one kernel (fpn_knn_point); False: the reference's own composition - the
+# (B,M,N) distance matrix formed with tensor operations and handed to select_top_k - which
+# the tests keep as the fused kernel's twin
+KNN_FUSED = True
+
+
 def knn_point(k, xyz1, xyz2):
     """k int, xyz1 (B,N,C) dataset, xyz2 (B,M,C) queries -> val (B,M,k) squared
     distances, idx (B,M,k) int32.  Reference: tf_grouping.py:49-74: the (B,M,N)
-    distance matrix sum((xyz1-xyz2)**2,-1) is built with ordinary tensor ops
-    (there: TF ops; here: torch ops on the device) and handed to select_top_k."""
+    distance matrix sum((xyz1-xyz2)**2,-1) goes through select_top_k and the first k
+    columns are sliced out; here one kernel forms each query's row on chip, runs the
+    same selection steps and writes the k columns (no (B,M,N) array)."""
+    if int(k) <= 0:
+        raise ValueError("SelectionSort expects positive k")
     _lib.require_device_tensor("xyz1", xyz1, torch.float32, 3)
     _lib.require_device_tensor("xyz2", xyz2, torch.float32, 3)
-    diff = xyz1[:, None, :, :] - xyz2[:, :, None, :]
-    dist = (diff * diff).sum(-1).contiguous()
-    outi, out = select_top_k(k, dist)
-    return out[:, :, :k].contiguous(), outi[:, :, :k].contiguous()
+    if xyz1.shape[0] != xyz2.shape[0] or xyz1.shape[2] != xyz2.shape[2]:
+        raise ValueError("knn_point expects xyz1 (B,N,C) and xyz2 (B,M,C) with the same batch size and channels")
+    _lib.same_device(xyz1, xyz2)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    if int(k) > n:
+        raise ValueError("knn_point: k = %d exceeds the %d dataset points" % (int(k), n))
+    if not KNN_FUSED:
+        diff = xyz1[:, None, :, :] - xyz2[:, :, None, :]
+        sq = diff * diff
+        dist = sq[..., 0]
+        for ch in range(1, c):          # left to right, as the kernel sums
+            dist = dist + sq[..., ch]
+        outi, out = select_top_k(k, dist.contiguous())
+        return out[:, :, :k].contiguous(), outi[:, :, :k].contiguous()
+    val = torch.empty((b, m, int(k)), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, m, int(k)), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        _lib.check(_lib.load().fpn_knn_point(b, n, c, m, int(k), _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(val),
+                                             _lib.ptr(idx), _lib.stream_of(xyz1)))
+    return val, idx

@@ -161,6 +161,20 @@ int fpn_select_top_k(int b, int n, int m, int k, const float *dist, int *outi, f
                      void *stream);
 
 /*
+ * k nearest dataset points of every query, knn_point(k, xyz1, xyz2) of
+ * models/tf_ops/grouping/tf_grouping.py:49-74 as one call: xyz1 (b,n,c) dataset, xyz2
+ * (b,m,c) queries -> val (b,m,k) squared distances, idx (b,m,k).  The reference builds
+ * the (b,m,n) matrix  reduce_sum((xyz1 - xyz2)**2, -1)  with TensorFlow ops (:65-67), sorts
+ * it with selectionSortLauncher (:69, tf_grouping.cpp:108) and slices the first k columns
+ * (:70-71).  Here the row of a query is formed in LDS - sum over the channels, left to
+ * right, of the rounded squares of the differences - the same k swap steps run on it
+ * (strict "<", lowest position among equal values), and only the k columns leave: neither
+ * the matrix nor the two (b,m,n) arrays exist.  1 <= k <= n <= 16384.
+ */
+int fpn_knn_point(int b, int n, int c, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                  void *stream);
+
+/*
  * One shared-MLP layer (1x1 convolution / fully connected) with everything the
  * reference applies after it fused in:
  *     acc  = x[r, 0:cin] . w            (fp32 MFMA, exact fp32 FMA chain)

@@ -153,6 +153,26 @@ def select_top_k(k, dist):
     return outi, out
 
 
+def knn_distances(xyz1, xyz2):
+    """The (b,m,n) float32 matrix of knn_point, models/tf_ops/grouping/tf_grouping.py:65-67:
+    sum over the channels of (xyz1 - xyz2)**2, every product and sum rounded to float32,
+    channels added left to right."""
+    xyz1 = np.asarray(xyz1, np.float32)
+    xyz2 = np.asarray(xyz2, np.float32)
+    sq = (xyz1[:, None, :, :] - xyz2[:, :, None, :]) ** 2
+    dist = sq[..., 0]
+    for ch in range(1, sq.shape[-1]):
+        dist = (dist + sq[..., ch]).astype(np.float32)
+    return np.ascontiguousarray(dist)
+
+
+def knn_point(k, xyz1, xyz2):
+    """knn_point, tf_grouping.py:49-74: the matrix above through the selection sort, first k
+    columns (:69-71) -> val (b,m,k), idx (b,m,k)."""
+    outi, out = select_top_k(k, knn_distances(xyz1, xyz2))
+    return np.ascontiguousarray(out[:, :, :k]), np.ascontiguousarray(outi[:, :, :k])
+
+
 # ---- reference-compiled loops (oracle/_ref) -------------------------------
 
 def ref_query_ball_point(radius, nsample, xyz1, xyz2):

@@ -77,3 +77,39 @@ def test_select_top_k_on_reference_outputs(device, tag, k):
     oi, ov = select_top_k(k, dev(GOLD["ss_%s_dist" % tag], device))
     np.testing.assert_array_equal(oi.cpu().numpy(), GOLD["ss_%s_idx_ref" % tag])
     np.testing.assert_array_equal(ov.cpu().numpy(), GOLD["ss_%s_val_ref" % tag])
+
+
+KNN = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_golden.npz"))
+
+
+def test_knn_point_on_the_reference_inputs(device):
+    """knn_point (one kernel, no distance matrix) on the inputs of the reference's own
+    models/tf_ops/grouping/test_knn.py:5-18 (seed 0, shapes (2,5,3) / (2,2,3)): the indices
+    of the three nearest are those of the script's float64 brute-force distances, the values
+    are those distances to float32 accuracy, and both equal the float32 matrix pushed through
+    the reference's selection_sort_cpu."""
+    from fpn.tf_ops.tf_grouping import knn_point
+    a = dev(KNN["ref_a_val"].astype(np.float32), device)
+    b = dev(KNN["ref_b_val"].astype(np.float32), device)
+    val, idx = knn_point(3, a, b)
+    np.testing.assert_array_equal(idx.cpu().numpy(), KNN["ref_top3_float64"])
+    want = np.take_along_axis(KNN["ref_dist_float64"], KNN["ref_top3_float64"].astype(np.int64), -1)
+    np.testing.assert_allclose(val.cpu().numpy(), want, rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(idx.cpu().numpy(), KNN["ref_idx_ref"])
+    np.testing.assert_array_equal(val.cpu().numpy(), KNN["ref_val_ref"])
+
+
+@pytest.mark.parametrize("tag", ["ties", "wide", "all"])
+def test_knn_point_ties_on_reference_outputs(device, tag):
+    """Lattice coordinates (many exactly equal distances; five channels; k = n): the order
+    among equal distances is the one the reference's swap sequence leaves."""
+    from fpn.tf_ops import tf_grouping
+    x1, x2, k = dev(KNN[tag + "_xyz1"], device), dev(KNN[tag + "_xyz2"], device), int(KNN[tag + "_k"])
+    for fused in (True, False):
+        tf_grouping.KNN_FUSED = fused
+        try:
+            val, idx = tf_grouping.knn_point(k, x1, x2)
+        finally:
+            tf_grouping.KNN_FUSED = True
+        np.testing.assert_array_equal(idx.cpu().numpy(), KNN[tag + "_idx_ref"], err_msg=str(fused))
+        np.testing.assert_array_equal(val.cpu().numpy(), KNN[tag + "_val_ref"], err_msg=str(fused))

@@ -446,6 +446,46 @@ def test_pointset_random_shapes(device):
         np.testing.assert_allclose(val.cpu().numpy(), np.sort(d2, -1)[..., :k], rtol=1e-5, atol=1e-6, err_msg=str(tag))
 
 
+@pytest.mark.parametrize("b,n,m,c,k", [(3, 2048, 37, 3, 32), (2, 1000, 5, 3, 128), (1, 64, 64, 3, 64), (2, 130, 9, 5, 7),
+                                       (4, 1, 3, 3, 1), (2, 4096, 2, 4, 3)])
+def test_knn_point_fused_kernel(device, b, n, m, c, k):
+    """fpn_knn_point against the oracle (float32 matrix + selection sort) and bit for bit
+    against the reference's composition on the device (tensor operations + select_top_k);
+    duplicated points give exact ties."""
+    from fpn.tf_ops import tf_grouping
+    rng = np.random.RandomState(n + m + k)
+    x1 = rng.random_sample((b, n, c)).astype(np.float32)
+    if n > 8:
+        x1[:, rng.permutation(n)[:n // 8]] = x1[:, rng.randint(0, n, n // 8)]
+    x2 = rng.random_sample((b, m, c)).astype(np.float32)
+    x2[:, ::2] = x1[:, rng.randint(0, n, len(range(0, m, 2)))]
+    val, idx = tf_grouping.knn_point(k, dev(x1, device), dev(x2, device))
+    wval, widx = O.knn_point(k, x1, x2)
+    np.testing.assert_array_equal(idx.cpu().numpy(), widx)
+    np.testing.assert_array_equal(val.cpu().numpy(), wval)
+    tf_grouping.KNN_FUSED = False
+    try:
+        mval, midx = tf_grouping.knn_point(k, dev(x1, device), dev(x2, device))
+    finally:
+        tf_grouping.KNN_FUSED = True
+    assert torch.equal(midx, idx) and torch.equal(mval, val)
+
+
+def test_knn_point_argument_checks(device):
+    from fpn.tf_ops.tf_grouping import knn_point
+    x1 = torch.zeros((2, 10, 3), device=device)
+    with pytest.raises(ValueError):
+        knn_point(0, x1, x1)
+    with pytest.raises(ValueError):
+        knn_point(11, x1, x1)
+    with pytest.raises(ValueError):
+        knn_point(2, x1, torch.zeros((3, 4, 3), device=device))
+    with pytest.raises(ValueError):
+        knn_point(2, x1, torch.zeros((2, 4, 2), device=device))
+    val, idx = knn_point(2, torch.zeros((0, 10, 3), device=device), torch.zeros((0, 4, 3), device=device))
+    assert val.shape == (0, 4, 2) and idx.shape == (0, 4, 2)
+
+
 def test_query_ball_point_multi_equals_single_queries(device):
     """One sweep for several radii (fpn_query_ball_point_multi) gives each radius the index
     table and the counts of its own fpn_query_ball_point call, bit for bit: full balls (early

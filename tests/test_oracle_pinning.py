@@ -153,3 +153,26 @@ def test_against_reference_loops_random():
             oi, ov = O.select_top_k(k, dist)
             np.testing.assert_array_equal(oi, ri)
             np.testing.assert_array_equal(ov, rv)
+
+
+def test_knn_point_oracle_on_the_reference_inputs():
+    """The oracle's knn_point on the inputs of models/tf_ops/grouping/test_knn.py:5-18 and on
+    the lattice sets of tests/golden/knn_golden.npz (whose *_ref outputs come from the
+    reference's selection_sort_cpu): same indices as the script's float64 distances give,
+    same bits as the reference's sort."""
+    knn = np.load(os.path.join(os.path.dirname(__file__), "golden", "knn_golden.npz"))
+    # the fixture's inputs ARE the script's: numpy's legacy generator, seed 0, two draws
+    rs = np.random.RandomState(0)
+    np.testing.assert_array_equal(knn["ref_a_val"], rs.random_sample((2, 5, 3)))
+    np.testing.assert_array_equal(knn["ref_b_val"], rs.random_sample((2, 2, 3)))
+    val, idx = O.knn_point(3, knn["ref_a_val"].astype(np.float32), knn["ref_b_val"].astype(np.float32))
+    np.testing.assert_array_equal(idx, knn["ref_top3_float64"])
+    np.testing.assert_array_equal(idx, knn["ref_idx_ref"])
+    np.testing.assert_array_equal(val, knn["ref_val_ref"])
+    for tag in ("ties", "wide", "all"):
+        val, idx = O.knn_point(int(knn[tag + "_k"]), knn[tag + "_xyz1"], knn[tag + "_xyz2"])
+        np.testing.assert_array_equal(idx, knn[tag + "_idx_ref"], err_msg=tag)
+        np.testing.assert_array_equal(val, knn[tag + "_val_ref"], err_msg=tag)
+    if O.have_ref():
+        oi, ov = O.ref_select_top_k(16, O.knn_distances(knn["ties_xyz1"], knn["ties_xyz2"]))
+        np.testing.assert_array_equal(oi[..., :16], knn["ties_idx_ref"])
