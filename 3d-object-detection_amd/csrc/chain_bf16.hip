@@ -1645,6 +1645,11 @@ __global__ __launch_bounds__(64 * kWaves, 1) void fp_head_pre_bf16_kernel(const 
     for (unsigned r = r0; r < r1; ++r) {
         float x[NP][8];
         floatx16 init[NP][4];
+        // ... and the other direction: this round's image was written by loads issued a round ago; they
+        // count in vmcnt like every load, and all of them (the image and the point's own channels) are
+        // wanted here
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0); lgkmcnt and expcnt untouched
+        lds_order();
 #pragma unroll
         for (int g = 0; g < NP; ++g) {
 #pragma unroll
@@ -1656,7 +1661,12 @@ __global__ __launch_bounds__(64 * kWaves, 1) void fp_head_pre_bf16_kernel(const 
                 for (int e = 0; e < 4; ++e) init[g][i >> 2][4 * (i & 3) + e] = (float)v[e];
             }
         }
-        lds_order();            // the image has been read: the next round's loads may overwrite it
+        // The next round's loads write the image through the memory pipe (LDS-direct loads), which the
+        // hardware does not order against this wave's outstanding ds_reads of the same bytes: the reads
+        // above must have RETURNED (lgkmcnt 0), not merely been issued, before the first such load goes
+        // out.  Their values are converted right below, so the wait costs nothing.
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt and expcnt untouched
+        lds_order();
         load_in(min(r + 1, r1 - 1));
         TileConst c2[2], c3[2];
         load_const(c2[0], lsh, 4 * h);
@@ -1841,9 +1851,8 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
     constexpr int U = ((NT2 + 1) / 2) * NT1 + (NT3 / 2) * NT2;
     constexpr size_t lds = (size_t)(U + kLdsAhead) * kUnitVecs * 16 + (32 * NT2 + 32 * NT3) * 4 + kWaves * 32 * NT3 * 4;
     static_assert(lds <= 160 * 1024, "the stream does not fit LDS");
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus < 1)
+    const int cus = current_device_cus();
+    if (cus < 1)
         return fail(FPN_E_LAUNCH, "sa_chain_bf16: cannot read the device's CU count");
     const unsigned balls = (unsigned)(p.rows / p.ns);
     const int np = groups_per_wave(p.ns);
@@ -1863,7 +1872,7 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
         const unsigned gg = g8 >= 8 ? g8 - g8 % 8 : g8;
         const unsigned pw = (balls + gg * 8 - 1) / (gg * 8);
         const void *fn8 = reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true, 8>);
-        if (hipFuncSetAttribute(fn8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess)
+        if (!allow_dynamic_lds(fn8, lds8))
             return fail(FPN_E_LAUNCH, "sa_chain_bf16: the device refuses %zu bytes of LDS per workgroup", lds8);
         hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true, 8>), dim3(gg), dim3(512), lds8, st, p, balls, pw);
         return check_launch("fpn_sa_chain_bf16");
@@ -1871,7 +1880,7 @@ int launch_sa_first(const SaParams &p, hipStream_t st)
     if (p.pre) {        // (with first-layer products there are no direct feature channels: KP = 4)
         const void *fn = np == 2 ? reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4, true>)
                                  : reinterpret_cast<const void *>(&sa_first_bf16_kernel<NT1, NT2, NT3, 1, 4, true>);
-        if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (!allow_dynamic_lds(fn, lds))
             return fail(FPN_E_LAUNCH, "sa_chain_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
         if (np == 2)
             hipLaunchKernelGGL((sa_first_bf16_kernel<NT1, NT2, NT3, 2, 4, true>), grid, block, lds, st, p, balls, per_wave);
@@ -2031,16 +2040,15 @@ static int fp_head_chain_bf16(long rows, int ca, int cb, const void *xa_any, int
     if (sa_persistent() && xa_bf16 && cb <= 8 && rows / (32 * np) < (1L << 31)) {
         constexpr int U = 2 * 5 + 8 + 8;
         constexpr size_t lds = (size_t)(U + kLdsAhead) * kUnitVecs * 16 + (3 * 128 + 256) * 4;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus < 1)
+        const int cus = current_device_cus();
+        if (cus < 1)
             return fail(FPN_E_LAUNCH, "fp_head_chain_bf16: cannot read the device's CU count");
         const unsigned rounds = (unsigned)(rows / (32 * np));
         const unsigned groups = std::min<unsigned>((unsigned)cus, (rounds + kWaves - 1) / kWaves);
         const unsigned per_wave = (rounds + groups * kWaves - 1) / (groups * kWaves);
         const void *fn = np == 2 ? reinterpret_cast<const void *>(&fp_head_lds_bf16_kernel<4, 2>)
                                  : reinterpret_cast<const void *>(&fp_head_lds_bf16_kernel<4, 1>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (!allow_dynamic_lds(fn, lds))
             return fail(FPN_E_LAUNCH, "fp_head_chain_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
         if (np == 2)
             hipLaunchKernelGGL((fp_head_lds_bf16_kernel<4, 2>), dim3(groups), dim3(64 * kWaves), lds, as_stream(stream), p, rounds, per_wave);
@@ -2082,9 +2090,8 @@ int fpn_fp_head_chain_pre_bf16(long rows, int cb, const void *pre_bf16, const fl
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
     p.sh2 = consts[3]; p.sh3 = consts[4]; p.w4 = consts[5]; p.b4 = consts[6];
     p.logits = logits;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus < 1)
+    const int cus = current_device_cus();
+    if (cus < 1)
         return fail(FPN_E_LAUNCH, "fp_head_chain_pre_bf16: cannot read the device's CU count");
     const int np = rows % 64 == 0 ? 2 : 1;
     // the weight stream, the constants, and every wave's image of its groups' rows of products
@@ -2094,7 +2101,7 @@ int fpn_fp_head_chain_pre_bf16(long rows, int cb, const void *pre_bf16, const fl
     const unsigned per_wave = (rounds + groups * kWaves - 1) / (groups * kWaves);
     const void *fn = np == 2 ? reinterpret_cast<const void *>(&fp_head_pre_bf16_kernel<2>)
                              : reinterpret_cast<const void *>(&fp_head_pre_bf16_kernel<1>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (!allow_dynamic_lds(fn, lds))
         return fail(FPN_E_LAUNCH, "fp_head_chain_pre_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
     if (np == 2)
         hipLaunchKernelGGL(fp_head_pre_bf16_kernel<2>, dim3(groups), dim3(64 * kWaves), lds, as_stream(stream), p, rounds, per_wave);

@@ -1461,9 +1461,8 @@ int launch_sa_persist(const SaChainParams &p, hipStream_t st)
                            kRegWaves * 32 * NT3 * 4;
     constexpr int per_cu = W3LDS ? 2 : 1;       // workgroups per CU (the kernel's launch bounds)
     static_assert(lds <= 160 * 1024 / per_cu, "the workgroups of a CU must fit LDS");
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus < 1)
+    const int cus = current_device_cus();
+    if (cus < 1)
         return fail(FPN_E_LAUNCH, "sa_chain: cannot read the device's CU count");
     const unsigned balls = (unsigned)(p.rows / p.ns);
     unsigned wgs = std::min<unsigned>((unsigned)cus * per_cu, (balls + kRegWaves - 1) / kRegWaves);
@@ -1471,7 +1470,7 @@ int launch_sa_persist(const SaChainParams &p, hipStream_t st)
     const unsigned per_wave = (balls + wgs * kRegWaves - 1) / (wgs * kRegWaves);
     const void *fn = p.pre ? reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, true, W3LDS>)
                            : reinterpret_cast<const void *>(&sa_persist_kernel<NT1, NT2, NT3, false, W3LDS>);
-    if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (!allow_dynamic_lds(fn, lds))
         return fail(FPN_E_LAUNCH, "sa_chain: the device refuses %zu bytes of LDS per workgroup", lds);
     if (p.pre)
         hipLaunchKernelGGL((sa_persist_kernel<NT1, NT2, NT3, true, W3LDS>), dim3(wgs), dim3(64 * kRegWaves), lds, st, p, balls,
@@ -1610,9 +1609,8 @@ static int sa_chain_f32(int b, int n, int m, int ns, int cf, int c1, int c2, int
     if (c1 == 32) {
         FPN_REQUIRE(!pre, "sa_chain: the 32-32-64 stack takes no first-layer products");
         FPN_REQUIRE(p.rows / 32 < (1L << 31), "sa_chain: too many rows");
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus < 1)
+        const int cus = current_device_cus();
+        if (cus < 1)
             return fail(FPN_E_LAUNCH, "sa_chain: cannot read the device's CU count");
         const unsigned groups = (unsigned)(p.rows / 32);
         unsigned wgs = std::min<unsigned>((unsigned)cus * 2, (groups + kRegWaves - 1) / kRegWaves);
@@ -1688,15 +1686,13 @@ int fpn_fp_head_chain_pre_f32(long rows, int cb, const float *pre, const float *
     p.w4 = layers[9]; p.b4 = layers[10];
     p.logits = logits;
     constexpr size_t lds = (size_t)2 * 4 * 4 * 256 * 16 + 1024 * 4;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus < 1)
+    const int cus = current_device_cus();
+    if (cus < 1)
         return fail(FPN_E_LAUNCH, "fp_head_chain_pre: cannot read the device's CU count");
     const unsigned rounds = (unsigned)(rows / 32);
     const unsigned wgs = std::min<unsigned>((unsigned)cus, (rounds + kRegWaves - 1) / kRegWaves);
     const unsigned per_wave = (rounds + wgs * kRegWaves - 1) / (wgs * kRegWaves);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fp_head_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
+    if (!allow_dynamic_lds(reinterpret_cast<const void *>(&fp_head_pre_kernel), lds))
         return fail(FPN_E_LAUNCH, "fp_head_chain_pre: the device refuses %zu bytes of LDS per workgroup", lds);
     hipLaunchKernelGGL(fp_head_pre_kernel, dim3(wgs), dim3(64 * kRegWaves), lds, as_stream(stream), p, rounds, per_wave);
     return check_launch("fpn_fp_head_chain_pre_f32");

@@ -26,6 +26,14 @@ inline int check_launch(const char *what)
 
 constexpr int kWave = 64;  // gfx950 wavefront width
 
+// Launch-time facts the persistent kernels size their grids by, asked of the runtime ONCE
+// per device (a step makes tens of such launches; api.cpp holds the tables):
+// the CU count of the calling thread's current device (0 if the runtime cannot tell), and
+// "kernel fn may use `bytes` of dynamic LDS per workgroup" - hipFuncSetAttribute is issued
+// only the first time a (kernel, device) pair asks for that much; false if it is refused.
+int current_device_cus();
+bool allow_dynamic_lds(const void *fn, size_t bytes);
+
 }  // namespace fpn
 
 #define FPN_REQUIRE(cond, ...)                                         \

@@ -779,7 +779,7 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         if (p.group_bias) p.group_bias += s * pin.sgb;
         p.y += s * pin.sy;
     }
-    __shared__ float part[(FLIP ? 2 : 1) * 4 * kFrRows * (kFrCols + 1)];
+    __shared__ float part[4 * kFrRows * (kFrCols + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int ncb = (p.cout + kFrCols - 1) / kFrCols;
@@ -887,21 +887,40 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         step(ring[0]);
     }
 
-    // partial tiles -> LDS: register r of tile u holds row (r&3) + 8(r>>2) + 4h, column 32u + l31
+    // partial tiles -> LDS: register r of tile u holds row (r&3) + 8(r>>2) + 4h, column 32u + l31.
+    // The Flipout form's second product goes through the SAME buffer after the first has been
+    // summed (two more barriers, half the LDS: 33 KB, under the 64 KiB a kernel gets by default).
     constexpr int LD = kFrCols + 1;
+    static_assert(sizeof(part) <= 64 * 1024, "the partial tiles must fit the default LDS limit");
     float *mine = part + wave * kFrRows * LD;
+    auto put = [&](const floatx16 (&a)[2]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            mine[rr * LD + 32 * u + l31] = acc[u][r];
-            if (FLIP) mine[4 * kFrRows * LD + rr * LD + 32 * u + l31] = accd[u][r];
-        }
-    __syncthreads();
-    // sum of the four waves' partial tiles in wave order, then the epilogue; a thread owns
-    // one column and eight rows
+            for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + 32 * u + l31] = a[u][r];
+    };
+    // sum of the four waves' partial tiles in wave order; a thread owns one column and eight rows
     const int c = tid & 63, col = col0 + c;
+    auto sum = [&](float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rr = (tid >> 6) + 4 * i;
+            float t = part[rr * LD + c];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) t += part[(w * kFrRows + rr) * LD + c];
+            v[i] = t;
+        }
+    };
+    float v[8], d[8];
+    put(acc);
+    __syncthreads();
+    sum(v);
+    if (FLIP) {
+        __syncthreads();
+        put(accd);
+        __syncthreads();
+        sum(d);
+    }
     if (col >= cout) return;
     const float sc = p.scale ? p.scale[col] : 1.f;
     const float sh = p.shift ? p.shift[col] : 0.f;
@@ -910,19 +929,12 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         const int rr = (tid >> 6) + 4 * i;
         const long rw = row0 + rr;
         if (rw >= p.rows) break;
-        float v = part[rr * LD + c];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) v += part[(w * kFrRows + rr) * LD + c];
-        if (FLIP) {
-            float d = part[(4 * kFrRows + rr) * LD + c];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) d += part[((4 + w) * kFrRows + rr) * LD + c];
-            v += d * p.sign_out[(rw / p.rows_per_group) * cout + col];
-        }
-        if (p.group_bias) v += p.group_bias[(rw / p.rows_per_group) * cout + col];
-        v = v * sc + sh;
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.y[rw * p.ldy + col] = v;
+        float y = v[i];
+        if (FLIP) y += d[i] * p.sign_out[(rw / p.rows_per_group) * cout + col];
+        if (p.group_bias) y += p.group_bias[(rw / p.rows_per_group) * cout + col];
+        y = y * sc + sh;
+        if (p.relu) y = fmaxf(y, 0.f);
+        p.y[rw * p.ldy + col] = y;
     }
 }
 
@@ -1137,10 +1149,9 @@ int fpn_shared_mlp_bf16(long rows, int cin, int cout, const float *x, int ldx, c
         const size_t lds = ((size_t)128 * (ldw + 8) + 2 * (size_t)kBM * kHS) * sizeof(__bf16);
         const int gbmode = !group_bias ? 0 : (p.rows_per_group % 32 == 0) ? 1 : (p.rows_per_group == 1) ? 2 : 3;
         const bool tail_ok = tail == 0 || gbmode == 0 || (nrb * kBM) % p.rows_per_group == 0;
-        int dev = 0, cus = 0;
+        int cus = 0;
         if (pool_rows == 0 && nrb >= 1024 && nrb <= INT32_MAX && lds <= 160 * 1024 && cin % 4 == 0 && ldx % 4 == 0 && tail_ok &&
-            (reinterpret_cast<uintptr_t>(x) & 15) == 0 && mlp_bf16_stream() && hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) {
+            (reinterpret_cast<uintptr_t>(x) & 15) == 0 && mlp_bf16_stream() && (cus = current_device_cus()) >= 8) {
             // two workgroups a CU when LDS allows (at most 256 registers), one with a bias row per row (its 64 bias
             // registers make 318)
             int streams = cus * (gbmode == 2 ? 1 : (int)std::min<size_t>(2, (160 * 1024) / lds)) / ncb;
@@ -1150,7 +1161,7 @@ int fpn_shared_mlp_bf16(long rows, int cin, int cout, const float *x, int ldx, c
                                : gbmode == 1 ? reinterpret_cast<const void *>(&shared_mlp_bf16_stream_kernel<1>)
                                : gbmode == 2 ? reinterpret_cast<const void *>(&shared_mlp_bf16_stream_kernel<2>)
                                              : reinterpret_cast<const void *>(&shared_mlp_bf16_stream_kernel<3>);
-                if (lds > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                if (!allow_dynamic_lds(fn, lds))
                     return fail(FPN_E_LAUNCH, "shared_mlp_bf16: the device refuses %zu bytes of LDS per workgroup", lds);
                 MlpParams q = p;
                 q.rows = nrb * kBM;

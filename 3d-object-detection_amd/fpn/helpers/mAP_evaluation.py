@@ -142,7 +142,15 @@ class Box3D:
         """Area of the overlap of the two ground rectangles (:162-167), with the
         reference's sanity assertion."""
         result, _ = _intersection_pair(self.packed(), other.packed(), device)
-        assert result <= self.width * self.length
+        # the reference's check is `result <= self.width * self.length` (:166); the overlap is the
+        # shoelace area of a clipped polygon and, for a box against itself or inside another,
+        # IS the rectangle's area up to rounding.  A shoelace sum adds products of coordinates,
+        # so its rounding error scales with sum |x_i y_j| (the box's distance from the origin
+        # squared), not with the area: the check allows exactly that much, nothing more.
+        x, y = self.ground_bbox_coords[:, 0], self.ground_bbox_coords[:, 1]
+        own = 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))))
+        slack = 16 * np.finfo(np.float64).eps * float(np.dot(np.abs(x), np.abs(np.roll(y, -1))) + np.dot(np.abs(y), np.abs(np.roll(x, -1))))
+        assert result <= max(own, self.width * self.length) + slack
         return result
 
     def get_intersection(self, other, device=None):

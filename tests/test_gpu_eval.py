@@ -106,6 +106,21 @@ def test_box3d_interface(device):
     assert a.get_height_intersection(c) == 0 and a.get_intersection(c) == 0 and a.get_iou(c) == 0
     want = om.quad_intersection_area(om.ground_corners(om.pack(a.serialize())), om.ground_corners(om.pack(c.serialize())))
     assert want > 0 and a.get_area_intersection(c) == want
+    # a box against itself, and a box wholly inside another, at awkward yaws and sizes: the overlap is
+    # the smaller box's own area up to rounding, and the sanity check inside must not trip on that rounding
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        yaw = rng.uniform(-3.2, 3.2)
+        qq = [float(np.cos(yaw / 2)), 0, 0, float(np.sin(yaw / 2))]
+        size = list(rng.uniform(0.3, 7.0, 3))
+        t = list(rng.uniform(-50, 50, 3))
+        inner = me.Box3D(sample_token="s", translation=t, size=size, rotation=qq, name="car")
+        outer = me.Box3D(sample_token="s", translation=t, size=[size[0] * 1.5, size[1] * 1.5, size[2]], rotation=qq, name="car")
+        own = size[0] * size[1]
+        assert abs(inner.get_area_intersection(inner) - own) <= 1e-9 * own
+        assert abs(inner.get_area_intersection(outer) - own) <= 1e-9 * own
+        assert abs(outer.get_area_intersection(inner) - own) <= 1e-9 * own
+        assert abs(inner.get_iou(inner) - 1.0) <= 1e-9
     assert me.get_ious([a, b], b) == [0.6, 1.0]
     assert me.get_ious([], b) == []
     with pytest.raises(AssertionError):
