@@ -118,34 +118,53 @@ __device__ __forceinline__ void opaque(WUnit &u)
         for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(u.w[a][m]));
 }
 
-struct RingFeed {
-    static constexpr int kMode = 0;
-    WUnit ring[kRing];
+// DEPTH units in flight (= the period of the slot numbers PH)
+template <int DEPTH>
+struct RingFeedT {
+    static constexpr int kMode = 0, kDepth = DEPTH;
+    WUnit ring[DEPTH];
     unsigned lane;
     __device__ __forceinline__ void start(const bf16x8 *__restrict__ ws, unsigned lane_, bf16x8 *)
     {
         lane = lane_;
 #pragma unroll
-        for (int i = 0; i < kRing; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
+        for (int i = 0; i < DEPTH; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
     }
     template <int PH>
-    __device__ __forceinline__ const WUnit &cur() const { return ring[PH % kRing]; }
-    // unit: the unit being multiplied; its slot is refilled with the unit kRing further on
+    __device__ __forceinline__ const WUnit &cur() const { return ring[PH % DEPTH]; }
+    // A kernel that does not consume its stream front to back (the seg tail interleaves two
+    // layers) names the units itself: kLook = how many consumption steps ahead a feed fetches,
+    // start_at(first(i)) = the unit consumed i-th, advance_at(next) = the unit consumed kLook
+    // steps after the one being multiplied.
+    static constexpr int kLook = DEPTH;
+    template <class First>
+    __device__ __forceinline__ void start_at(First &&first, unsigned lane_, bf16x8 *)
+    {
+        lane = lane_;
+        static_for<0, DEPTH>([&](auto I) { load_unit(ring[decltype(I)::value], first(I), lane); });
+    }
+    template <int PH>
+    __device__ __forceinline__ void advance_at(const bf16x8 *__restrict__ next)
+    {
+#ifndef FPN_RING_NOLOAD
+        load_unit(ring[PH % DEPTH], next, lane);
+#else       // timing-only build (wrong results): no loads; the fragments stay opaque so that every MFMA remains
+        opaque(ring[PH % DEPTH]);
+#endif
+    }
+    // unit: the unit being multiplied; its slot is refilled with the unit DEPTH further on
     template <int PH>
     __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
     {
-#ifndef FPN_RING_NOLOAD
-        load_unit(ring[PH % kRing], unit + (size_t)kRing * kUnitVecs, lane);
-#else       // timing-only build (wrong results): no loads; the fragments stay opaque so that every MFMA remains
-        opaque(ring[PH % kRing]);
-#endif
+        advance_at<PH>(unit + (size_t)DEPTH * kUnitVecs);
     }
     template <int PH>
     __device__ __forceinline__ void sync() {}
 };
+using RingFeed = RingFeedT<kRing>;
 
 struct CoopFeed {
-    static constexpr int kMode = 1;
+    static constexpr int kMode = 1, kDepth = 4;
     WUnit frag[4];          // (indexed by stream position mod 4; kFeedRead + 1 of them are live)
     bf16x8 stage[kFeedStage];
     bf16x8 *lds;            // kFeedSlots * kUnitVecs vectors, shared by the workgroup
@@ -184,8 +203,27 @@ struct CoopFeed {
     }
     template <int PH>
     __device__ __forceinline__ const WUnit &cur() const { return frag[PH % 4]; }
+    static constexpr int kLook = kFeedAhead + kFeedStage;
+    template <class First>
+    __device__ __forceinline__ void start_at(First &&first, unsigned lane_, bf16x8 *ring)
+    {
+        lane = lane_;
+        lds = ring;
+        mine = (threadIdx.x >> 6) * 64 + lane_;
+        bf16x8 head[kFeedAhead];
+        static_for<0, kFeedAhead>([&](auto I) { head[decltype(I)::value] = first(I)[mine]; });
+        static_for<0, kFeedStage>([&](auto I) {
+            stage[decltype(I)::value] = first(std::integral_constant<int, kFeedAhead + decltype(I)::value>{})[mine];
+        });
+#pragma unroll
+        for (int i = 0; i < kFeedAhead; ++i) lds[i * kUnitVecs + mine] = head[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kFeedRead; ++i) read_unit_rt(frag[i], i);
+        __syncthreads();
+    }
     template <int PH>
-    __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
+    __device__ __forceinline__ void advance_at(const bf16x8 *__restrict__ next)
     {
         // (FPN_FEED_NO*: timing-only builds that drop one part of the feed; wrong results)
 #ifndef FPN_FEED_NOREAD
@@ -195,8 +233,13 @@ struct CoopFeed {
 #endif
 #ifndef FPN_FEED_NOFILL
         lds[((PH + kFeedAhead) % kFeedSlots) * kUnitVecs + mine] = stage[PH % kFeedStage];
-        stage[PH % kFeedStage] = unit[(size_t)(kFeedAhead + kFeedStage) * kUnitVecs + mine];
+        stage[PH % kFeedStage] = next[mine];
 #endif
+    }
+    template <int PH>
+    __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
+    {
+        advance_at<PH>(unit + (size_t)(kFeedAhead + kFeedStage) * kUnitVecs);
     }
     template <int PH>
     __device__ __forceinline__ void sync()
@@ -215,7 +258,7 @@ struct CoopFeed {
 constexpr int kLdsAhead = 2;
 
 struct LdsFeed {
-    static constexpr int kMode = 2;
+    static constexpr int kMode = 2, kDepth = kRing;
     WUnit frag[kLdsAhead];
     const bf16x8 *lds;      // the stream in LDS
     const bf16x8 *base;     // the stream in memory: the layers name their units by address there
@@ -440,7 +483,7 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
     TileConst csh[2];
     static_for<0, U>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
-        constexpr int slot = (R0 + S) % kRing;
+        constexpr int slot = (R0 + S) % Feed::kDepth;
         constexpr int ntile = 2 * tp + 1 < NT ? 2 : 1;
         unit_mfma<j == 0, true, j, ntile>(acc[set], feed.template cur<slot>(), in);
         feed.template advance<slot>(ws + (size_t)S * kUnitVecs);
@@ -487,7 +530,7 @@ __device__ __forceinline__ void layer_t_from(Out (&out)[NP][NT], const Act (&in)
     floatx16 acc[2][2][NP];
     static_for<0, U>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
-        constexpr int slot = (R0 + S) % kRing;
+        constexpr int slot = (R0 + S) % Feed::kDepth;
         constexpr int ntile = 2 * tp + 1 < NT ? 2 : 1;
         if constexpr (j == 0) unit_mfma_from<ntile>(acc[set], feed.template cur<slot>(), in, csh);
         else unit_mfma<false, true, j, ntile>(acc[set], feed.template cur<slot>(), in);
@@ -620,7 +663,7 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
         const bf16x8 *wt = ws + (size_t)(t0 / 2) * NJ * kUnitVecs;
         static_for<0, 2 * NJ>([&](auto I) {
             constexpr int S = decltype(I)::value, set = S / NJ, j = S % NJ;
-            constexpr int slot = (R0 + S) % kRing;
+            constexpr int slot = (R0 + S) % Feed::kDepth;
             unit_mfma<j == 0, false, j>(acc[set], feed.template cur<slot>(), in);
             feed.template advance<slot>(wt + (size_t)S * kUnitVecs);
             // the other accumulator pair holds the two tiles before these; the very first
@@ -922,6 +965,212 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
     if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
         for (int i = 0; i < 7; ++i) reinterpret_cast<long long *>(p.logits)[32 + i] = stamp[i];
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// seg tail, conv6 and conv7 INTERLEAVED.  conv6 is a short layer (two units per pair of
+// output tiles): run on its own it waits for every pair's shifts and pays an epilogue per
+// eight MFMAs - 8.3 k cycles of a wave for 2.0 k of matrix time - and its 512-wide result
+// holds 128 registers per point group until conv7 is done.  Here conv6 is produced in
+// chunks of 64 channels (one pair) that conv7's accumulators - all eight output tiles live
+// at once - consume at once, and a chunk's units and epilogues ride between conv7's:
+//
+//     A A | B0 B0 B0 B0 [A A] B1 B1 B1 B1 | B0 B0 B0 B0 [A A] B1 B1 B1 B1 | ...        (8 times)
+//
+//   A  = a unit of conv6, chunk c+1 (input tile 0 / 1 of point_feat -> acc6),
+//   Bj = a unit of conv7 that multiplies tile j of chunk c (one unit per pair of conv7's
+//        output tiles); while the B1 units issue, tile 0 of chunk c+1 is finished into the
+//        register tile the B0 units have just released, and tile 1 during the next B0 units.
+// No epilogue of conv6 is exposed, its shifts are requested six units before they are
+// wanted, and the registers it frees make room for NP = 2 point groups per wave: every
+// weight fragment is used twice, which halves what the feed has to deliver per MFMA.
+// Every accumulator sees the same MFMAs in the same order as in seg_tail_bf16_kernel (conv7
+// still adds its input tiles in ascending order), and the epilogues are the same
+// instructions: the logits are the same bits.  The stream is the same too; the kernel reads
+// its units in the order above (TailOrder::pos).
+// ---------------------------------------------------------------------------
+// P: pairs of conv7's output tiles per pass (4: all eight tiles at once; 2: two passes over conv6 - its 64
+// MFMAs per point group are then done twice, 15 % more matrix work, and conv7's live accumulators halve)
+template <int P>
+struct TailOrder {
+    static constexpr int kU6 = 16, kStream = 80;      // conv6: 16 units, conv6 + conv7: 80 units of the stream
+    static constexpr int kStep = 2 * P + 2;           // units of a step: P x B0, A A, P x B1 (the last step has no A)
+    static constexpr int kPass = 2 + 7 * kStep + 2 * P, kPasses = 4 / P, kFused = kPasses * kPass;
+    // what the unit consumed s-th is: kind 0 = A (conv6), 1 = B0, 2 = B1; idx = input tile of A / pair of B inside
+    // the pass; c = step (-1: the prologue's A A)
+    struct What { int pass, c, kind, idx; };
+    static constexpr What what(int S)
+    {
+        const int pass = S / kPass, s = S % kPass;
+        if (s < 2) return {pass, -1, 0, s};
+        const int t = s - 2;
+        if (t < 7 * kStep) {
+            const int c = t / kStep, r = t % kStep;
+            if (r < P) return {pass, c, 1, r};
+            if (r < P + 2) return {pass, c, 0, r - P};
+            return {pass, c, 2, r - P - 2};
+        }
+        const int q = t - 7 * kStep;
+        return q < P ? What{pass, 7, 1, q} : What{pass, 7, 2, q - P};
+    }
+    // stream position of the unit consumed s-th
+    static constexpr int pos(int S)
+    {
+        if (S >= kFused) return kStream + (S - kFused);
+        const What w = what(S);
+        if (w.kind == 0) return 2 * (w.c + 1) + w.idx;                   // conv6, chunk c + 1
+        return kU6 + (w.pass * P + w.idx) * 16 + 2 * w.c + (w.kind - 1);  // conv7, pair, input tile 2 c (+ 1)
+    }
+};
+
+template <int NP, int P, class Feed>
+__global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const TailParams pin)
+{
+    using Order = TailOrder<P>;
+    static_assert(NP <= P, "a tile's riders need one unit per point group");
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)logical_block(pin.copy_vecs) * kWaves + (threadIdx.x >> 6)) * (32 * NP);
+    // conv6's shifts - the frustum's row of 512 floats - wait in the wave's OWN piece of LDS (each wave reads only
+    // what it wrote: no barrier) and come back one tile at a time, a unit or two before the epilogue that adds
+    // them: 16 registers instead of 64 for two tiles held six units ahead of their use
+    __shared__ float shift6[kWaves][512];
+    // two passes: the first pass's half of conv7's output (64 registers of operand fragments for two point
+    // groups) has nothing to do during the second pass and waits in the wave's own piece of LDS as well
+    // (vector v of a lane at [v][lane]: consecutive 16-byte slots, no bank conflicts) - held in registers it
+    // pushed the compiler into parking values in accumulator registers and copying whole accumulator tiles around
+    constexpr bool kPark = Order::kPasses == 2;
+    constexpr int kParkVecs = NP * P * 2 * 2;        // point groups x tiles of a pass x fragments
+    __shared__ bf16x8 park7[kPark ? kWaves * kParkVecs * 64 : 1];
+    if (row0 >= pin.rows) return;       // (never with a cooperative feed: the host launches it on full workgroups only)
+    TailParams p = pin;
+    if (pin.copy_vecs) {
+        const size_t f = scalar_index(row0 / pin.n);
+        p.ws += f * pin.copy_vecs;
+        p.w10 += f * (128 * 2);
+    }
+    const bf16x8 *ws = p.ws;
+    Feed feed;
+    feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, feed_ring<Feed>());
+    bf16x8 *park = park7 + (kPark ? (threadIdx.x >> 6) * (kParkVecs * 64) + lane : 0);
+
+    float *sh6 = shift6[threadIdx.x >> 6];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(p.gshift + (row0 / p.n) * 512);   // (a wave's points lie in one frustum)
+        const float4 lo = src[lane], hi = src[64 + lane];
+        reinterpret_cast<float4 *>(sh6)[lane] = lo;
+        reinterpret_cast<float4 *>(sh6)[64 + lane] = hi;
+    }
+    Act pf[NP][2];
+#pragma unroll
+    for (int g = 0; g < NP; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) pf[g][t].m[s] = p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h];
+
+    Act a7[NP][8];
+    {
+        floatx16 acc7[P][2][NP];
+        floatx16 acc6[2][NP];
+        Act a6c[NP][2];
+        TileConst c6;
+        static_for<0, Order::kFused>([&](auto I) {
+            constexpr int S = decltype(I)::value, slot = S % Feed::kDepth;
+            constexpr typename Order::What w = Order::what(S);
+            if constexpr (w.kind == 0) unit_mfma<w.idx == 0, true, w.idx>(acc6, feed.template cur<slot>(), pf);
+            else unit_mfma<(w.c == 0 && w.kind == 1), true, w.kind - 1>(acc7[w.idx], feed.template cur<slot>(), a6c);
+            feed.template advance_at<slot>(ws + (size_t)Order::pos(S + Feed::kLook) * kUnitVecs);
+            // riders.  During the B0 units of step c tile 1 of chunk c is finished (one point group per unit), during
+            // its B1 units tile 0 of chunk c + 1; in a pass's prologue tile 0 of chunk 0 right behind the second A
+            // unit - the one epilogue of conv6 that nothing hides.  The shifts of the tile finished next are read
+            // from LDS as soon as the register tile is free.
+            constexpr bool ride1 = w.kind == 1 && w.idx < NP;                   // tile 1 of chunk c, group idx
+            constexpr bool ride0 = w.kind == 2 && w.idx < NP && w.c < 7;        // tile 0 of chunk c + 1, group idx
+            if constexpr (ride1) finish(a6c[w.idx][1], acc6[1][w.idx], c6);
+            if constexpr (ride0) finish(a6c[w.idx][0], acc6[0][w.idx], c6);
+            if constexpr (w.kind == 0 && w.idx == 0 && w.c < 0) load_const(c6, sh6, 4 * h);                      // chunk 0, tile 0
+            if constexpr (w.kind == 0 && w.idx == 0 && w.c >= 0) load_const(c6, sh6, 64 * (w.c + 1) + 4 * h);    // chunk c + 1, tile 0
+            if constexpr (w.kind == 2 && w.idx == P - 1 && w.c < 7) load_const(c6, sh6, 64 * (w.c + 1) + 32 + 4 * h);   // chunk c + 1, tile 1
+            sched_unit<Feed::kMode, 4 * NP, 4, (ride0 || ride1) ? (28 + 4 * NP - 1) / (4 * NP) : 1>();
+            if constexpr (w.kind == 0 && w.idx == 1 && w.c < 0) {
+#pragma unroll
+                for (int g = 0; g < NP; ++g) finish(a6c[g][0], acc6[0][g], c6);
+                load_const(c6, sh6, 32 + 4 * h);    // chunk 0, tile 1
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            feed.template sync<slot>();
+            // a pass's end: conv7's epilogue for its tiles
+            if constexpr (S % Order::kPass == Order::kPass - 1) {
+                TileConst c7;
+#pragma unroll
+                for (int tp = 0; tp < P; ++tp)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        load_const(c7, p.sh7, 32 * (2 * (w.pass * P + tp) + u) + 4 * h);
+#pragma unroll
+                        for (int g = 0; g < NP; ++g) finish(a7[g][2 * (w.pass * P + tp) + u], acc7[tp][u][g], c7);
+                    }
+                if constexpr (kPark && w.pass == 0) {
+#pragma unroll
+                    for (int g = 0; g < NP; ++g)
+#pragma unroll
+                        for (int t = 0; t < 2 * P; ++t)
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) park[((g * 2 * P + t) * 2 + m) * 64] = a7[g][t].m[m];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        if constexpr (kPark) {
+#pragma unroll
+            for (int g = 0; g < NP; ++g)
+#pragma unroll
+                for (int t = 0; t < 2 * P; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) a7[g][t].m[m] = park[((g * 2 * P + t) * 2 + m) * 64];
+        }
+    }
+
+    constexpr int U8 = units_of(256, 128);
+    ws += (size_t)Order::kStream * kUnitVecs;
+    Act a8[NP][4];
+    floatx16 a9[NP][4];
+    layer_t<NP, 8, 4, Order::kFused % Feed::kDepth>(a8, a7, ws, p.sh8, feed, h);
+    ws += U8 * kUnitVecs;
+    layer_t<NP, 4, 4, (Order::kFused + U8) % Feed::kDepth>(a9, a8, ws, p.sh9, feed, h);
+
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        // Monte-Carlo dropout before the head (models/FPointNet_Bayes.py:92): bit c of word j
+        // of the point's mask keeps channel 32 j + c, kept activations count twice
+        if (p.drop) {
+            const uint4 keep = *reinterpret_cast<const uint4 *>(p.drop + (row0 + 32 * g + pt) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned word = (j == 0 ? keep.x : j == 1 ? keep.y : j == 2 ? keep.z : keep.w) >> (4 * h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a9[g][j][r] *= (word >> (8 * (r >> 2) + (r & 3))) & 1u ? 2.f : 0.f;
+            }
+        }
+        // conv10 (128 -> 2) in fp32 on the vector ALU, as in seg_tail_bf16_kernel
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 *w = reinterpret_cast<const float4 *>(p.w10 + (32 * j + 8 * q + 4 * h) * 2);
+                const float4 wa = w[0], wb = w[1];
+                s0 = fmaf(a9[g][j][4 * q + 0], wa.x, s0); s1 = fmaf(a9[g][j][4 * q + 0], wa.y, s1);
+                s0 = fmaf(a9[g][j][4 * q + 1], wa.z, s0); s1 = fmaf(a9[g][j][4 * q + 1], wa.w, s1);
+                s0 = fmaf(a9[g][j][4 * q + 2], wb.x, s0); s1 = fmaf(a9[g][j][4 * q + 2], wb.y, s1);
+                s0 = fmaf(a9[g][j][4 * q + 3], wb.z, s0); s1 = fmaf(a9[g][j][4 * q + 3], wb.w, s1);
+            }
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (h == 0)
+            *reinterpret_cast<float2 *>(p.logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1985,10 +2234,29 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
     p.logits = logits;
     p.copy_vecs = copy_vecs;
     p.drop = reinterpret_cast<const unsigned *>(drop_mask);
-    if (use_coop(rows, 1, copy_vecs, n))
-        hipLaunchKernelGGL(seg_tail_bf16_kernel<CoopFeed>, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
-    else
-        hipLaunchKernelGGL(seg_tail_bf16_kernel<RingFeed>, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+    // FPN_BF16_TAIL: "layers" = the layer-by-layer kernel (the twin the tests compare with), "fused1" / "fused2" =
+    // conv6 interleaved with conv7, one / two point groups per wave; default: fused2 where a frustum holds whole
+    // 64-point groups, else fused1
+    const char *form = std::getenv("FPN_BF16_TAIL");
+    const std::string f = form ? form : "";
+    if (f == "layers") {
+        if (use_coop(rows, 1, copy_vecs, n))
+            hipLaunchKernelGGL(seg_tail_bf16_kernel<CoopFeed>, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+        else
+            hipLaunchKernelGGL(seg_tail_bf16_kernel<RingFeed>, grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+        return check_launch("fpn_v1_seg_tail_bf16");
+    }
+    const int np = (f == "fused1" || n % 64 != 0) ? 1 : 2;
+    const bool coop = use_coop(rows, np, copy_vecs, n);
+    if (np == 2) {      // two point groups per wave: conv7 in two passes of two pairs (all eight tiles' accumulators
+                        // for 64 points are the whole accumulator file: the compiler then spills)
+        // (every wave reads the stream itself: with each fragment used twice the vector memory path keeps up, and
+        // the workgroup's LDS ring - 80 more registers, a barrier every two units - measured slower here)
+        hipLaunchKernelGGL((seg_tail_fused_bf16_kernel<2, 2, RingFeedT<3>>), grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
+    } else {
+        if (coop) hipLaunchKernelGGL((seg_tail_fused_bf16_kernel<1, 4, CoopFeed>), grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+        else hipLaunchKernelGGL((seg_tail_fused_bf16_kernel<1, 4, RingFeed>), grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
+    }
     return check_launch("fpn_v1_seg_tail_bf16");
 }
 

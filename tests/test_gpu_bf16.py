@@ -253,6 +253,52 @@ def test_bf16_weight_feeds_agree_bit_for_bit(device, monkeypatch, B, N, dropout)
         assert torch.equal(got["ring"][k], got["lds"][k]), k
 
 
+@pytest.mark.parametrize("B,N,dropout", [(4, 256, False), (16, 1024, True), (13, 96, True), (3, 160, False), (8, 128, True)])
+def test_bf16_tail_forms_agree_bit_for_bit(device, monkeypatch, B, N, dropout):
+    """The seg tail with conv6 interleaved into conv7 (one and two point groups per wave, both
+    weight feeds) against the layer-by-layer kernel: every accumulator sees the same MFMAs
+    in the same order, so the logits - and everything after them - are the same bits; shared
+    stream (plain v1) and one stream per frustum copy (Flipout, with the dropout bits).
+    96- and 160-point frustums have no whole 64-point groups: the two-group form falls back
+    to one group there, 13 x 96 and 3 x 160 also leave workgroups partly filled."""
+    from fpn import bayes, plan, synthetic, variables
+    forms = ("layers", "fused1", "fused2")
+    # Flipout: per-copy streams
+    st = variables.VariableStore(device, seed=4)
+    bp = bayes.BayesPlan(st, 3, mc_dropout=dropout, precision="bf16")
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=B)
+    pcd, ohd = dev(pc, device), dev(oh, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    noise = bp.sample_noise(2, B, g, N)
+    got = {}
+    for form in forms:
+        for feed in ("ring", "lds"):
+            monkeypatch.setenv("FPN_BF16_TAIL", form)
+            monkeypatch.setenv("FPN_BF16_FEED", feed)
+            ep = bp.forward(pcd, ohd, 2, noise=noise)
+            got[form, feed] = {k: ep[k].clone() for k in ("mask_logits", "box_output", "stage1_center")}
+    assert float(got["layers", "ring"]["mask_logits"].abs().max()) > 0
+    for key, res in got.items():
+        for k in res:
+            assert torch.equal(res[k], got["layers", "ring"][k]), (key, k)
+    # the deterministic network: one shared stream
+    st = variables.VariableStore(device, seed=6)
+    plan.init_variables(st, 4, True)
+    st.randomize_batch_norm(7)
+    net = plan.V1Plan(st, 4, True, precision="bf16")
+    pc, oh = synthetic.make_frustums(B, N, 4, seed=B + 1)
+    pcd, ohd = dev(pc, device), dev(oh, device)
+    got = {}
+    for form in forms:
+        for feed in ("ring", "lds"):
+            monkeypatch.setenv("FPN_BF16_TAIL", form)
+            monkeypatch.setenv("FPN_BF16_FEED", feed)
+            got[form, feed] = net.forward(pcd, ohd)["mask_logits"].clone()
+    for key, res in got.items():
+        assert torch.equal(res, got["layers", "ring"]), key
+
+
 @pytest.mark.parametrize("rows,cin,cout,pool,gb", [
     (300, 67, 59, 0, 0), (4096, 448, 128, 0, 0), (1024, 643, 200, 32, 0), (2048, 256, 1024, 64, 0),
     (1536, 128, 256, 128, 0), (2048, 640, 128, 0, 256), (4096, 256, 512, 512, 0), (640, 130, 128, 0, 5),
