@@ -2252,7 +2252,8 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
                         // for 64 points are the whole accumulator file: the compiler then spills)
         // (every wave reads the stream itself: with each fragment used twice the vector memory path keeps up, and
         // the workgroup's LDS ring - 80 more registers, a barrier every two units - measured slower here)
-        hipLaunchKernelGGL((seg_tail_fused_bf16_kernel<2, 2, RingFeedT<3>>), grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
+        // (two, three or four units in flight: 0.440 / 0.443 / 0.436 ms - the weights' latency is not what is left)
+        hipLaunchKernelGGL((seg_tail_fused_bf16_kernel<2, 2, RingFeed>), grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
     } else {
         if (coop) hipLaunchKernelGGL((seg_tail_fused_bf16_kernel<1, 4, CoopFeed>), grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);
         else hipLaunchKernelGGL((seg_tail_fused_bf16_kernel<1, 4, RingFeed>), grid_for(rows, 1), dim3(64 * kWaves), 0, as_stream(stream), p);

@@ -42,8 +42,8 @@ def main():
     w10c = w10.repeat(b, 1).contiguous()
     consts_pc = ops.pointer_table([net.p[s][2] for s in ("conv7", "conv8", "conv9")] + [w10c, net.p["conv10"][2]])
     flop = rows * 2.0 * (64 * 512 + 512 * 256 + 256 * 128 + 128 * 128 + 128 * 2)
-    for form in ("layers", "fused1", "fused2"):
-        for feed in ("ring", "lds"):
+    variants = [("layers", "ring"), ("layers", "lds"), ("fused1", "ring"), ("fused1", "lds"), ("fused2", "ring")]
+    for form, feed in variants:
             os.environ["FPN_BF16_TAIL"], os.environ["FPN_BF16_FEED"] = form, feed
             t = timed(lambda: ops.v1_seg_tail_bf16(point_feat, n, gbias, net._tail_ws, net._tail_consts, logits))
             tc = timed(lambda: ops.v1_seg_tail_bf16(point_feat, n, gbias, copies, consts_pc, logits, copy_vecs=per // 8))
