@@ -452,6 +452,11 @@ def pointset_ops(dev, frustums=256, reps=20):
     new_xyz = tf_sampling.gather_point(xyz, idx)
     gi, _ = tf_grouping.query_ball_point(0.4, NS, xyz, new_xyz)
     feat2 = torch.randn((B, M, C), device=dev)
+    from fpn import inference
+    det_logits = torch.randn((B, N, 2), device=dev)
+    det_box = torch.randn((B, 59), device=dev)
+    det_c1 = torch.randn((B, 3), device=dev)
+    det_rot = torch.rand((B,), device=dev)
     cases = {
         "farthest_point_sample(2048->128)": (lambda: tf_sampling.farthest_point_sample(M, xyz), 12 * N + 4 * M),
         "gather_point(128)": (lambda: tf_sampling.gather_point(xyz, idx), 4 * M + 24 * M),
@@ -461,6 +466,10 @@ def pointset_ops(dev, frustums=256, reps=20):
         "three_nn(2048,128)": (lambda: tf_interpolate.three_nn(xyz, new_xyz), 12 * (N + M) + 24 * N),
         "three_nn_interpolate(2048,128,c=64)": (lambda: tf_interpolate.three_nn_interpolate(xyz, new_xyz, feat2),
                                                 12 * (N + M) + 4 * M * C + 4 * N * C),
+        "knn_point(2048,128,k=32)": (lambda: tf_grouping.knn_point(32, xyz, new_xyz), 12 * (N + M) + 8 * M * 32),
+        # logits + box vector + centre + angle in, 20 doubles + the mask bits out
+        "detection_records(2048)": (lambda: inference.detection_records(det_logits, det_box, det_c1, det_rot, True),
+                                    8 * N + 59 * 4 + 12 + 4 + 160 + N // 8),
     }
     out = {}
     # FPN_POINTSET_SYNC=1 (counter runs): one launch on the device at a time, so that a
