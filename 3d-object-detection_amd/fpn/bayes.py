@@ -31,14 +31,27 @@ FLIPOUT_EPS = float(np.finfo(np.float32).eps)   # tfp adds eps to softplus(rho)
 PLAIN = ("fc3-stage1", "fc3")
 
 
-def init_variables(store, pc_channels=3, rho_mean=-3.0, rho_std=0.1, seed=3):
-    """Weights of the v1 topology without batch norm plus a 'rho' per Flipout layer
-    (N(rho_mean, rho_std), tfp's default untransformed-scale initialiser)."""
+# the one layer of models/frustum_pointnet.py without batch norm (:225; every other layer,
+# conv10 and fc3-stage1 included, is built with the default bn=True, :15,30,150,203)
+NO_BN = ("fc3",)
+
+
+def init_variables(store, pc_channels=3, rho_mean=-3.0, rho_std=0.1, seed=3, bn=False, flipout_outputs=False):
+    """Weights of the v1 topology plus a 'rho' per Flipout layer (N(rho_mean, rho_std), tfp's
+    default untransformed-scale initialiser).  bn: batch-norm variables for every layer but
+    the last (models/frustum_pointnet.py); flipout_outputs: the two output layers are Flipout
+    layers too (there: DenseFlipout by default, :30-41,203,225; in FPointNet_Bayes.py they
+    are plain Dense, :115,136)."""
     _plan.init_variables(store, pc_channels, bn=False)
     g = torch.Generator(device="cpu")
     g.manual_seed(int(seed))
     for scope, cin, cout, _, _ in _plan.layer_table(pc_channels):
-        if scope in PLAIN or (scope + "/rho") in store:
+        if bn and scope not in NO_BN:
+            store.get_variable(scope + "/bn/gamma", (cout,), "ones")
+            store.get_variable(scope + "/bn/beta", (cout,), "zeros")
+            store.get_variable(scope + "/bn/moving_mean", (cout,), "zeros")
+            store.get_variable(scope + "/bn/moving_variance", (cout,), "ones")
+        if (scope in PLAIN and not flipout_outputs) or (scope + "/rho") in store:
             continue
         store[scope + "/rho"] = torch.randn((cin, cout), generator=g) * rho_std + rho_mean
     return store
@@ -64,7 +77,8 @@ class Noise(dict):
 class BayesPlan:
     """S Monte-Carlo forward passes of the Flipout network."""
 
-    def __init__(self, store, pc_channels=3, chunk_frustums=None, mc_dropout=False, chain=True, precision="fp32"):
+    def __init__(self, store, pc_channels=3, chunk_frustums=None, mc_dropout=False, chain=True, precision="fp32",
+                 bn=False, flipout_outputs=False, recentre_box_input=True):
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
         if precision == "bf16" and not chain:
@@ -80,8 +94,16 @@ class BayesPlan:
         # layer is a plain product with it).  Monte-Carlo dropout (before the 2-channel
         # head) is a keep-bit mask applied inside the tail kernel.
         self.chain = chain
-        init_variables(store, pc_channels)
+        # bn: inference batch norm after every layer but the last; flipout_outputs: the two output
+        # layers draw weights too - together the network of models/frustum_pointnet.py:108-295
+        # recentre_box_input=False: the box stack reads the object points as the T-net saw them, not shifted
+        # by its centre estimate (models/frustum_pointnet.py:210-214 forms the shifted points and does not use them)
+        self.bn = bn
+        self.flipout_outputs = flipout_outputs
+        self.recentre_box_input = recentre_box_input
+        init_variables(store, pc_channels, bn=bn, flipout_outputs=flipout_outputs)
         self.table = _plan.layer_table(pc_channels)
+        self.flip_scopes = [scope for scope, _, _, _, _ in self.table if flipout_outputs or scope not in PLAIN]
         self._ones = {}
         self._w6_glob = None
         self._sig_all = None
@@ -94,7 +116,7 @@ class BayesPlan:
         conv9's 128 outputs (bit c of word j keeps channel 32j + c; rate 0.5)."""
         dev = self.store.device
         noise = Noise()
-        flip = [(scope, cin, cout) for scope, cin, cout, _, _ in self.table if scope not in PLAIN]
+        flip = [(scope, cin, cout) for scope, cin, cout, _, _ in self.table if scope in self.flip_scopes]
         up4 = lambda v: (v + 3) // 4 * 4          # noqa: E731  (every slot starts on a 16-byte boundary)
         total_e = sum(up4(cin * cout) for _, cin, cout in flip)
         total_w = sum(up4(cin) + up4(cout) for _, cin, cout in flip)
@@ -128,7 +150,7 @@ class BayesPlan:
         if hit is None or hit[0] != self.store.version:
             parts = []
             for scope, cin, cout, _, _ in self.table:
-                if scope not in PLAIN:
+                if scope in self.flip_scopes:
                     parts.append(self.store[scope + "/rho"].reshape(-1))
                     if (cin * cout) % 4:      # the slots of Noise.eps_all start on 16-byte boundaries
                         parts.append(parts[-1].new_zeros(4 - (cin * cout) % 4))
@@ -136,15 +158,27 @@ class BayesPlan:
         return hit[1]
 
     # ---- layers --------------------------------------------------------------
-    def _flip(self, x, scope, dw, si, so, rows_per_group, relu=True, pool_rows=0, out=None):
+    def _fold(self, scope):
+        """(scale or None, shift) of a layer's epilogue: bias and, with bn, the inference
+        batch norm folded (fpn.variables.VariableStore.folded)."""
+        return self.store.folded(scope, self.bn and scope not in NO_BN)
+
+    def _scale(self, scope):
+        """The epilogue scale as a tensor (ones without batch norm)."""
+        scale, shift = self._fold(scope)
+        return scale if scale is not None else self._one(shift.shape[0])
+
+    def _flip(self, x, scope, dw, si, so, rows_per_group, relu=True, pool_rows=0, out=None, **kw):
         """One Flipout layer on the rows of x; dw (cin,cout), si (groups,cin), so
         (groups,cout)."""
+        scale, shift = self._fold(scope)
         return ops.shared_mlp_flipout(x, self.store[scope + "/weights"], dw.reshape(1, *dw.shape), x.shape[0],
-                                      si, so, rows_per_group, scale=None, shift=self.store[scope + "/biases"],
-                                      relu=relu, pool_rows=pool_rows, out=out)
+                                      si, so, rows_per_group, scale=scale, shift=shift,
+                                      relu=relu, pool_rows=pool_rows, out=out, **kw)
 
-    def _plain(self, x, scope):
-        return ops.shared_mlp(x, self.store[scope + "/weights"], None, self.store[scope + "/biases"], relu=False)
+    def _plain(self, x, scope, out=None):
+        scale, shift = self._fold(scope)
+        return ops.shared_mlp(x, self.store[scope + "/weights"], scale, shift, relu=False, out=out)
 
     def default_chunk(self, n):
         return max(1, min(1024, (1 << 30) // (n * 3700)))
@@ -275,9 +309,17 @@ class BayesPlan:
         """[w_eff, ones, bias] per layer: the `layers` table of a chain kernel."""
         t = []
         for scope, layout in zip(scopes, layouts):
-            bias = self.store[scope + "/biases"]
-            t += [self._eff(scope, nz, layout), self._one(bias.shape[0]), bias]
+            t += [self._eff(scope, nz, layout), self._scale(scope), self._fold(scope)[1]]
         return t
+
+    def _eff_head(self, nz, copies):
+        """conv10's per-copy effective weights (copies, 128, 2) with its batch-norm scale folded into the
+        columns (the tail kernels add a shift after the product, they have no scale slot), and that shift."""
+        w10 = self._eff("conv10", nz, 0)
+        scale, shift = self._fold("conv10")
+        if scale is not None:
+            w10 = (w10.view(copies, 128, 2) * scale).reshape(copies, 256)
+        return w10, shift
 
     def _forward_chunk_chain(self, pc, one_hot, nz, samples, drop_mask=None, outs=None):
         """pc (samples * frustums, n, c): the frustum block repeated once per sample;
@@ -290,25 +332,33 @@ class BayesPlan:
         st = self.store
         outs = outs or {}
 
-        def conv(x, scope, rpg, relu=True):        # fully connected Flipout layers: one row per copy
+        def conv(x, scope, rpg, relu=True, out=None):        # fully connected Flipout layers: one row per copy
             dw, si, so = nz[scope]
+            scale, shift = self._fold(scope)
             return ops.shared_mlp_flipout(x, st[scope + "/weights"], dw.contiguous(), x.shape[0] // samples,
                                           si.contiguous(), so.contiguous(), rpg,
-                                          scale=None, shift=st[scope + "/biases"], relu=relu)
+                                          scale=scale, shift=shift, relu=relu, out=out)
 
         bf16 = self.precision == "bf16"
+
+        def scaled(scope, w, dw):
+            """bf16 streams hold the batch-norm scale inside the weights (one rounding of w * scale): the
+            column scale commutes with the output signs, so mean and perturbation are scaled (fp32) before
+            the effective weights are formed."""
+            scale, _ = self._fold(scope)
+            return (w, dw) if scale is None else (w * scale, dw * scale)
 
         def streams(scopes, first=None):           # bf16: per-copy weight streams of a kernel
             layers = [] if first is None else [first]
             for k in scopes:
                 dw, si, so = nz[k]
-                layers.append((st[k + "/weights"], dw, si, so))
+                layers.append(scaled(k, st[k + "/weights"], dw) + (si, so))
             return ops.flipout_streams_bf16(b, layers)
 
         def obj_chain(scopes, box, delta, out):
             if bf16:
                 ws, cv = streams(scopes[1:])
-                ct = [self._eff(scopes[0], nz, 0), self._one(128)] + [st[k + "/biases"] for k in scopes]
+                ct = [self._eff(scopes[0], nz, 0), self._scale(scopes[0])] + [self._fold(k)[1] for k in scopes]
                 ops.v1_obj_chain_bf16(obj2d, m, box, delta, ws, ops.pointer_table(ct), out, copy_vecs=cv)
             else:
                 t = self._chain_tensors(scopes, nz, (0,) + (1,) * (len(scopes) - 1))
@@ -321,8 +371,8 @@ class BayesPlan:
         point_feat = torch.empty((b * n, 64), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         if bf16:
             ws, cv = streams(("conv2", "conv3", "conv4", "conv5"))
-            head = [self._eff("conv1", nz, 0), self._one(64)] + \
-                [st[k + "/biases"] for k in ("conv1", "conv2", "conv3", "conv4", "conv5")]
+            head = [self._eff("conv1", nz, 0), self._scale("conv1")] + \
+                [self._fold(k)[1] for k in ("conv1", "conv2", "conv3", "conv4", "conv5")]
             ops.v1_seg_head_bf16(pc.reshape(b * n, c), n, ws, ops.pointer_table(head), point_feat, gcat, copy_vecs=cv)
             del ws
         else:
@@ -332,25 +382,26 @@ class BayesPlan:
         w6 = st["conv6/weights"]
         if self._w6_glob is None or self._w6_glob[0] != st.version:
             self._w6_glob = (st.version, w6[64:].contiguous())       # rows of the frustum-constant inputs
+        scale6, shift6 = self._fold("conv6")
         gshift = ops.shared_mlp_flipout(gcat, self._w6_glob[1], dw6[:, 64:].contiguous(), b // samples,
-                                        si6[:, 64:].contiguous(), so6.contiguous(), 1, scale=None,
-                                        shift=st["conv6/biases"], relu=False)
+                                        si6[:, 64:].contiguous(), so6.contiguous(), 1, scale=scale6,
+                                        shift=shift6, relu=False)
         logits = outs.get("mask_logits")
         if logits is None:
             logits = torch.empty((b, n, 2), dtype=torch.float32, device=dev)
+        w10, shift10 = self._eff_head(nz, b)
         if bf16:
+            w6p, dw6p = scaled("conv6", w6[:64], dw6[:, :64])
             ws, cv = streams(("conv7", "conv8", "conv9"),
-                             first=(w6[:64], dw6[:, :64], si6[:, :64] if si6.stride(0) % 4 == 0 else si6[:, :64].contiguous(),
-                                    so6))
-            tail = [st[k + "/biases"] for k in ("conv7", "conv8", "conv9")] + \
-                [self._eff("conv10", nz, 0), st["conv10/biases"]]
+                             first=(w6p, dw6p if dw6p.stride(1) == 512 and dw6p.stride(2) == 1 else dw6p.contiguous(),
+                                    si6[:, :64] if si6.stride(0) % 4 == 0 else si6[:, :64].contiguous(), so6))
+            tail = [self._fold(k)[1] for k in ("conv7", "conv8", "conv9")] + [w10, shift10]
             ops.v1_seg_tail_bf16(point_feat, n, gshift, ws, ops.pointer_table(tail), logits, copy_vecs=cv,
                                  drop_mask=drop_mask)
             del ws
         else:
-            tail = [self._eff("conv6", nz, 1, rows=64), self._one(512)] + \
-                self._chain_tensors(("conv7", "conv8", "conv9"), nz, (1, 2, 2)) + \
-                [self._eff("conv10", nz, 0), st["conv10/biases"]]
+            tail = [self._eff("conv6", nz, 1, rows=64), self._scale("conv6")] + \
+                self._chain_tensors(("conv7", "conv8", "conv9"), nz, (1, 2, 2)) + [w10, shift10]
             ops.v1_seg_tail(point_feat, n, gshift, ops.pointer_table(tail), logits, per_frustum=True,
                             drop_mask=drop_mask)
         del point_feat, head, tail
@@ -365,16 +416,22 @@ class BayesPlan:
         obj_chain(("conv-reg1-stage1", "conv-reg2-stage1", "conv-reg3-stage1"), False, None, tcat)
         t = conv(tcat, "fc1-stage1", 1)
         t = conv(t, "fc2-stage1", 1)
-        center_delta = ops.shared_mlp(t, st["fc3-stage1/weights"], None, st["fc3-stage1/biases"], relu=False,
-                                      out=outs.get("center_delta"))
+        if self.flipout_outputs:
+            center_delta = conv(t, "fc3-stage1", 1, relu=False, out=outs.get("center_delta"))
+        else:
+            center_delta = self._plain(t, "fc3-stage1", out=outs.get("center_delta"))
 
         # box net (FPointNet_Bayes.py:99-117); the kernel subtracts center_delta on load
         bcat = torch.zeros((b, 512 + 3), dtype=torch.float32, device=dev)
         bcat[:, 512:] = one_hot
-        obj_chain(("conv-reg1", "conv-reg2", "conv-reg3", "conv-reg4"), True, center_delta, bcat)
+        obj_chain(("conv-reg1", "conv-reg2", "conv-reg3", "conv-reg4"), True,
+                  center_delta if self.recentre_box_input else None, bcat)
         t = conv(bcat, "fc1", 1)
         t = conv(t, "fc2", 1)
-        output = ops.shared_mlp(t, st["fc3/weights"], None, st["fc3/biases"], relu=False, out=outs.get("box_output"))
+        if self.flipout_outputs:
+            output = conv(t, "fc3", 1, relu=False, out=outs.get("box_output"))
+        else:
+            output = self._plain(t, "fc3", out=outs.get("box_output"))
         return {"mask_logits": logits, "mask": mask, "object_point_indices": sel, "mask_xyz_mean": mean,
                 "center_delta": center_delta, "box_output": output}
 
@@ -404,9 +461,10 @@ class BayesPlan:
         w6 = self.store["conv6/weights"]
         gbias = ops.shared_mlp_flipout(gcat, w6[64:].contiguous(), dw6[64:].reshape(1, 1027, 512).contiguous(),
                                        b, si6[:, 64:].contiguous(), so6, 1, scale=None, shift=None, relu=False)
+        scale6, shift6 = self._fold("conv6")
         a = ops.shared_mlp_flipout(point_feat, w6[:64].contiguous(), dw6[:64].reshape(1, 64, 512).contiguous(),
-                                   b * n, si6[:, :64].contiguous(), so6, n, scale=None,
-                                   shift=self.store["conv6/biases"], relu=True, group_bias=gbias)
+                                   b * n, si6[:, :64].contiguous(), so6, n, scale=scale6,
+                                   shift=shift6, relu=True, group_bias=gbias)
         del point_feat
         a = conv(a, "conv7", n)
         a = conv(a, "conv8", n)
@@ -426,9 +484,9 @@ class BayesPlan:
         tcat[:, 256:] = one_hot
         t = conv(tcat, "fc1-stage1", 1)
         t = conv(t, "fc2-stage1", 1)
-        center_delta = self._plain(t, "fc3-stage1")
+        center_delta = conv(t, "fc3-stage1", 1, relu=False) if self.flipout_outputs else self._plain(t, "fc3-stage1")
         stage1_center = center_delta + mean
-        obj_new = (obj - center_delta[:, None, :]).reshape(b * m, 3)
+        obj_new = ((obj - center_delta[:, None, :]) if self.recentre_box_input else obj).reshape(b * m, 3)
 
         # box net (FPointNet_Bayes.py:99-117)
         t = conv(obj_new, "conv-reg1", m)
@@ -439,7 +497,7 @@ class BayesPlan:
         bcat[:, 512:] = one_hot
         t = conv(bcat, "fc1", 1)
         t = conv(t, "fc2", 1)
-        output = self._plain(t, "fc3")
+        output = conv(t, "fc3", 1, relu=False) if self.flipout_outputs else self._plain(t, "fc3")
 
         ep = {"mask_logits": logits, "mask": mask, "object_point_indices": sel, "mask_xyz_mean": mean,
               "center_delta": center_delta, "stage1_center": stage1_center, "box_output": output}

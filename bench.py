@@ -235,7 +235,7 @@ def pmc_kernel_prefix(obs_name):
     summaries (tools/pmc_summary.py strips the namespace and the argument list)."""
     fixed = {"v1_seg_tail": "seg_tail_reg_kernel", "v1_seg_head": "seg_head_reg_kernel",
              "v1_obj_chain_box": "obj_chain_reg_kernel<true>", "v1_obj_chain_tnet": "obj_chain_reg_kernel<false>",
-             "v1_seg_tail_bf16": "seg_tail_bf16_kernel", "v1_seg_head_bf16": "seg_head_bf16_kernel",
+             "v1_seg_tail_bf16": ("seg_tail_fused_bf16_kernel", "seg_tail_bf16_kernel"), "v1_seg_head_bf16": "seg_head_bf16_kernel",
              "v1_obj_chain_box_bf16": "obj_chain_bf16_kernel<true", "v1_obj_chain_tnet_bf16": "obj_chain_bf16_kernel<false",
              "fp_head_chain": "fp_head_reg_kernel", "fp_head_chain_pre": "fp_head_pre_kernel", "fp_head_chain_pre_bf16": "fp_head_pre_bf16_kernel", "fp_head_chain_bf16": ("fp_head_lds_bf16_kernel", "fp_head_bf16_kernel")}
     if obs_name in fixed:

@@ -17,7 +17,17 @@ from . import v1_numpy as V
 PLAIN = ("fc3-stage1", "fc3")
 
 
-def flipout_dense(x, params, scope, dw, s_in, s_out, rows_per_group, relu, dtype=np.float64):
+NO_BN = ("fc3",)       # models/frustum_pointnet.py:225: the last layer alone is built with bn=False
+
+
+def batch_norm(y, params, scope, dtype=np.float64):
+    """Keras BatchNormalization in inference mode (models/frustum_pointnet.py:23-24,36-37; epsilon
+    1e-3, the Keras default): (y - mean) * gamma / sqrt(var + eps) + beta."""
+    inv = params[scope + "/bn/gamma"].astype(dtype) / np.sqrt(params[scope + "/bn/moving_variance"].astype(dtype) + V.BN_EPS)
+    return y * inv + (params[scope + "/bn/beta"].astype(dtype) - params[scope + "/bn/moving_mean"].astype(dtype) * inv)
+
+
+def flipout_dense(x, params, scope, dw, s_in, s_out, rows_per_group, relu, dtype=np.float64, bn=False):
     """x (rows,cin); dw (cin,cout); s_in (groups,cin); s_out (groups,cout)."""
     w = params[scope + "/weights"].astype(dtype)
     b = params[scope + "/biases"].astype(dtype)
@@ -25,21 +35,33 @@ def flipout_dense(x, params, scope, dw, s_in, s_out, rows_per_group, relu, dtype
     so = np.repeat(s_out.astype(dtype), rows_per_group, axis=0)
     x = x.astype(dtype)
     y = x @ w + b + ((x * si) @ dw.astype(dtype)) * so
+    if bn:
+        y = batch_norm(y, params, scope, dtype)
     return np.maximum(y, 0) if relu else y
 
 
-def forward_sample(pc, one_hot, params, noise_s, dtype=np.float64, mask_override=None, dropout_keep=None):
+def forward_sample(pc, one_hot, params, noise_s, dtype=np.float64, mask_override=None, dropout_keep=None, bn=False,
+                   recentre_box_input=True):
     """One Monte-Carlo pass (FPointNet_Bayes.py:167-185).  noise_s[scope] =
     (dW (cin,cout), s_in (B,cin), s_out (B,cout)) for every Flipout layer.
     dropout_keep (B,N,128) bool, if given: layers.Dropout(rate=0.5) before the 2-channel
     head (:92) ACTIVE, as in Monte-Carlo dropout: kept activations are scaled by
-    1 / (1 - rate) = 2, the others are zero."""
+    1 / (1 - rate) = 2, the others are zero.
+    bn=True and noise for 'fc3-stage1' / 'fc3': the network of models/frustum_pointnet.py:108-295
+    instead - batch norm after every layer but the last (conv10 and fc3-stage1 included: their
+    conv_bn_act / Dense_bn_act calls keep the default bn=True, :51,104) and Flipout output layers."""
     B, N, _ = pc.shape
     M = V.NUM_OBJECT_POINT
 
     def conv(x, scope, rpg, relu=True):
         dw, si, so = noise_s[scope]
-        return flipout_dense(x, params, scope, dw, si, so, rpg, relu, dtype)
+        return flipout_dense(x, params, scope, dw, si, so, rpg, relu, dtype, bn=bn and scope not in NO_BN)
+
+    def output_layer(x, scope):
+        if scope in noise_s:
+            return conv(x, scope, 1, relu=False)
+        y = V.dense(x, params, scope, False, False, dtype)
+        return batch_norm(y, params, scope, dtype) if bn and scope not in NO_BN else y
 
     x = pc.reshape(B * N, -1)
     a = conv(x, "conv1", N)
@@ -64,16 +86,19 @@ def forward_sample(pc, one_hot, params, noise_s, dtype=np.float64, mask_override
     t = np.concatenate([t.reshape(B, M, -1).max(1), one_hot.astype(dtype)], 1)
     t = conv(t, "fc1-stage1", 1)
     t = conv(t, "fc2-stage1", 1)
-    delta = V.dense(t, params, "fc3-stage1", False, False, dtype)        # layers.Dense(3) :136
+    delta = output_layer(t, "fc3-stage1")                                # layers.Dense(3) :136
     stage1 = delta + mean
-    t = conv((obj - delta[:, None, :]).reshape(B * M, 3), "conv-reg1", M)
+    # models/frustum_pointnet.py:210-214 forms the re-centred points and then feeds the box
+    # stack the un-shifted ones (recentre_box_input=False); FPointNet_Bayes.py:99-101 shifts
+    box_in = obj - delta[:, None, :] if recentre_box_input else obj
+    t = conv(box_in.reshape(B * M, 3), "conv-reg1", M)
     t = conv(t, "conv-reg2", M)
     t = conv(t, "conv-reg3", M)
     t = conv(t, "conv-reg4", M)
     t = np.concatenate([t.reshape(B, M, -1).max(1), one_hot.astype(dtype)], 1)
     t = conv(t, "fc1", 1)
     t = conv(t, "fc2", 1)
-    out = V.dense(t, params, "fc3", False, False, dtype)                 # layers.Dense(59) :115
+    out = output_layer(t, "fc3")                                         # layers.Dense(59) :115
     ep = {"mask_logits": logits, "mask": mask, "object_point_indices": idx, "mask_xyz_mean": mean,
           "center_delta": delta, "stage1_center": stage1, "box_output": out}
     V.parse_output(out, ep, dtype)

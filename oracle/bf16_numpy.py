@@ -114,40 +114,70 @@ class Weights:
         return (y if scale is None else y * scale.astype(np.float64)) + shift.astype(np.float64)
 
 
+FIRST = ("conv1", "conv-reg1-stage1", "conv-reg1")      # first layers of the stacks: float32 weights, split operands
+NO_BN = ("fc3",)                                        # models/frustum_pointnet.py:126
+
+
 class FlipoutWeights(Weights):
     """One Monte-Carlo sample: noise_s[scope] = (dW (cin,cout), s_in (B,cin), s_out (B,cout));
     the convolutions see W_eff[b] = W + diag(s_in[b]) dW diag(s_out[b]) in float32 (signs are
-    +-1: the sum is the one rounding), no batch norm."""
+    +-1: the sum is the one rounding).  bn: batch norm after every layer but the last
+    (models/frustum_pointnet.py); the product then scales mean and perturbation by the
+    batch-norm scale in float32 BEFORE it forms the effective weights of a bf16 stream (the
+    column scale commutes with the output signs), and multiplies conv10's float32 effective
+    weights by it; a stack's first layer keeps unscaled effective weights and the kernel
+    multiplies (then splits) them."""
 
-    def __init__(self, params, noise_s):
-        super().__init__(params, False)
+    def __init__(self, params, noise_s, bn=False):
+        super().__init__(params, bn)
         self.noise = noise_s
+
+    def _fold(self, scope):
+        return fold(self.params, scope, self.bn and scope not in NO_BN)
 
     def conv(self, scope):
         dw, si, so = self.noise[scope]
-        w = self.params[scope + "/weights"].astype(np.float64)
-        eff = (w[None] + si[:, :, None] * np.asarray(dw, np.float64)[None] * so[:, None, :]).astype(f32)
-        return eff, None, self.params[scope + "/biases"].astype(f32)
+        scale, shift = self._fold(scope)
+        w = self.params[scope + "/weights"].astype(f32)
+        dw = np.asarray(dw, f32)
+        pre = scale is not None and scope not in FIRST and scope != "conv10"
+        if pre:
+            w, dw = (w * scale).astype(f32), (dw * scale).astype(f32)
+        eff = (w.astype(np.float64)[None] + si[:, :, None] * dw.astype(np.float64)[None] * so[:, None, :]).astype(f32)
+        if scale is not None and scope == "conv10":
+            eff = (eff * scale).astype(f32)
+        return eff, (scale if scope in FIRST else None), shift
 
     def dense(self, x, scope, relu):
-        if scope not in self.noise:
-            return V.dense(x, self.params, scope, False, relu, np.float64)
-        dw, si, so = self.noise[scope]
+        scale, shift = self._fold(scope)
         w = self.params[scope + "/weights"].astype(np.float64)
-        y = x @ w + self.params[scope + "/biases"].astype(np.float64) + ((x * si) @ np.asarray(dw, np.float64)) * so
+        y = x @ w
+        if scope in self.noise:
+            dw, si, so = self.noise[scope]
+            y = y + ((x * si) @ np.asarray(dw, np.float64)) * so
+        y = (y if scale is None else y * scale.astype(np.float64)) + shift.astype(np.float64)
         return np.maximum(y, 0.0) if relu else y
+
+    def summed_magnitude(self, x, scope):
+        scale, shift = self._fold(scope)
+        w = np.abs(self.params[scope + "/weights"].astype(np.float64))
+        if scale is not None:
+            w = w * np.abs(scale.astype(np.float64))
+        return np.abs(x) @ w + np.abs(shift.astype(np.float64))
 
     def conv6_frustum_part(self, g):
         dw, si, so = self.noise["conv6"]
+        scale, shift = self._fold("conv6")
         w = self.params["conv6/weights"].astype(np.float64)[64:]
-        return g @ w + self.params["conv6/biases"].astype(np.float64) + ((g * si[:, 64:]) @ np.asarray(dw, np.float64)[64:]) * so
+        y = g @ w + ((g * si[:, 64:]) @ np.asarray(dw, np.float64)[64:]) * so
+        return (y if scale is None else y * scale.astype(np.float64)) + shift.astype(np.float64)
 
 
 def _rows(w, lo, hi):
     return w[..., lo:hi, :]
 
 
-def forward(pc, one_hot, weights, mask_override=None, dropout_keep=None):
+def forward(pc, one_hot, weights, mask_override=None, dropout_keep=None, recentre_box_input=True):
     """The v1 topology under the rounding model.  pc (B,N,C) float32, one_hot (B,3);
     weights: Weights or FlipoutWeights; dropout_keep (B,N,128) bool or None (kept activations
     of conv9 doubled, the others zero: layers.Dropout(0.5) active, FPointNet_Bayes.py:92).
@@ -200,7 +230,8 @@ def forward(pc, one_hot, weights, mask_override=None, dropout_keep=None):
     scale["center_delta"] = W.summed_magnitude(t, "fc3-stage1")
     scale["stage1_center"] = scale["center_delta"] + np.abs(ep["mask_xyz_mean"])
     # box net (frustum_pointnets_v1.py:93-138); the kernel subtracts the float32 centre while loading
-    obj_new = (obj.astype(f32) - delta.astype(f32)[:, None, :]).astype(f32)
+    # (recentre_box_input=False: models/frustum_pointnet.py:214 feeds the un-shifted points)
+    obj_new = (obj.astype(f32) - delta.astype(f32)[:, None, :]).astype(f32) if recentre_box_input else obj.astype(f32)
     t = stack(obj_new, [s for s, _ in V.BOX_CONV])
     for s, _ in V.BOX_FC:
         t = W.dense(t, s, True)

@@ -107,16 +107,21 @@ def v1_draw(device, seed, B, N):
     return model, exact
 
 
-def bayes_setup(device, seed, dropout, precision="bf16"):
-    """A Flipout plan whose biases are N(0, 0.1) draws of the seed's own generator."""
+def bayes_setup(device, seed, dropout, precision="bf16", full=False, chain=True):
+    """A Flipout plan whose biases are N(0, 0.1) draws of the seed's own generator.  full: the
+    network of models/frustum_pointnet.py - batch norm (random statistics) after every layer
+    but the last, Flipout output layers, box stack on the un-shifted object points."""
     from fpn import bayes, variables
     st = variables.VariableStore(device, seed=4000 + seed)
-    bp = bayes.BayesPlan(st, 3, mc_dropout=dropout, precision=precision)
+    bp = bayes.BayesPlan(st, 3, mc_dropout=dropout, precision=precision, bn=full, flipout_outputs=full, recentre_box_input=not full,
+                         chain=chain)
     gb = torch.Generator()
     gb.manual_seed(5000 + seed)
     for k in list(st.keys()):
         if k.endswith("/biases"):
             st[k] = torch.randn(st[k].shape, generator=gb) * 0.1
+    if full:
+        st.randomize_batch_norm(5500 + seed)
     return st, bp
 
 
@@ -141,7 +146,7 @@ def keep_mask(noise, s):
     return ((bits[..., None] >> np.arange(32)) & 1).reshape(bits.shape[0], bits.shape[1], 128).astype(bool)
 
 
-def bayes_compare(st, ep, noise, pc, oh, samples, model, exact):
+def bayes_compare(st, ep, noise, pc, oh, samples, model, exact, full=False):
     """Accumulate into model / exact the worst errors of the given samples of a Flipout
     forward `ep` against the rounding model and the textbook float64 estimator."""
     params = st.numpy()
@@ -151,33 +156,33 @@ def bayes_compare(st, ep, noise, pc, oh, samples, model, exact):
         nz = flipout_noise_of_sample(st, noise, s)
         keep = keep_mask(noise, s)
         kw = {} if keep is None else {"dropout_keep": keep}
-        weights = Q.FlipoutWeights(params, nz)
-        m = Q.forward(pc, oh, weights, **kw)
-        x = BN.forward_sample(pc64, oh64, p64, nz, **kw)
+        weights = Q.FlipoutWeights(params, nz, bn=full)
+        m = Q.forward(pc, oh, weights, recentre_box_input=not full, **kw)
+        x = BN.forward_sample(pc64, oh64, p64, nz, bn=full, recentre_box_input=not full, **kw)
         got = ep["mask_logits"][s].cpu().numpy()
         mag = m["summed_magnitude"]["mask_logits"]
         _merge(model, "mask_logits", magnitude_error(got, m["mask_logits"], mag))
         _merge(exact, "mask_logits", magnitude_error(got, x["mask_logits"], mag))
         mask = ep["mask"][s].cpu().numpy()
-        m = Q.forward(pc, oh, weights, mask_override=mask, **kw)
-        x = BN.forward_sample(pc64, oh64, p64, nz, mask_override=mask, **kw)
+        m = Q.forward(pc, oh, weights, mask_override=mask, recentre_box_input=not full, **kw)
+        x = BN.forward_sample(pc64, oh64, p64, nz, mask_override=mask, bn=full, recentre_box_input=not full, **kw)
         np.testing.assert_array_equal(ep["object_point_indices"][s].cpu().numpy(), m["object_point_indices"])
         for k in KEYS[1:]:
             _merge(model, k, magnitude_error(ep[k][s].cpu().numpy(), m[k], m["summed_magnitude"][k]))
             _merge(exact, k, magnitude_error(ep[k][s].cpu().numpy(), x[k], m["summed_magnitude"][k]))
 
 
-def bayes_draw(device, seed, B, N, dropout, S=2):
+def bayes_draw(device, seed, B, N, dropout, S=2, full=False):
     """The Flipout network (per-copy weight streams), S samples."""
     from fpn import synthetic
-    st, bp = bayes_setup(device, seed, dropout)
+    st, bp = bayes_setup(device, seed, dropout, full=full)
     pc, oh = synthetic.make_frustums(B, N, 3, seed=6000 + seed)
     g = torch.Generator(device=device)
     g.manual_seed(7000 + seed)
     noise = bp.sample_noise(S, B, g, N)
     ep = bp.forward(dev(pc, device), dev(oh, device), S, noise=noise)
     model, exact = {}, {}
-    bayes_compare(st, ep, noise, pc, oh, range(S), model, exact)
+    bayes_compare(st, ep, noise, pc, oh, range(S), model, exact, full=full)
     return model, exact
 
 
@@ -243,6 +248,7 @@ CASES = {
     "v1": lambda device, seed: v1_draw(device, seed, 4, 256),
     "flipout": lambda device, seed: bayes_draw(device, seed, 4, 256, False),
     "flipout_dropout": lambda device, seed: bayes_draw(device, seed, 4, 256, True),
+    "flipout_batch_norm": lambda device, seed: bayes_draw(device, seed, 4, 256, False, full=True),
     "v2": lambda device, seed: v2_draw(device, seed, 1, 1024),
 }
 

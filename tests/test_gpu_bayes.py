@@ -193,11 +193,11 @@ def test_keras_and_bayes_model_surfaces(device):
         o1 = bdet.predict([pc, oh])
         o2 = bdet.predict([pc, oh])
         ep = FPointNet_Bayes.get_model(dev(pc, device), dev(oh, device), False, nsamples=3)
-        _, d11 = frustum_pointnet.frustum_pointnet()
+        _, d11 = frustum_pointnet.frustum_pointnet(point_cloud_shape=(1024, 3))
         o11 = d11.predict([pc, oh])
     assert len(o1) == 6 and not np.array_equal(o1[0], o2[0])       # every predict draws fresh weights
     assert ep["box_output"].shape == (3, 4, 59) and ep["mc_statistics"].shape == (4, 30)
-    assert len(o11) == 11 and o11[1].shape == (4, 1024)
+    assert len(o11) == 11 and o11[0].shape == (4, 1024) and o11[1].shape == (4, 1024, 2)
 
 
 @pytest.mark.parametrize("chain,N", [(True, 160), (False, 128)])
@@ -324,3 +324,88 @@ def test_flipout_layer_random_shapes(device):
             close(got.cpu().numpy(), np.concatenate(want, 0), 1e-4)
         except AssertionError as e:
             raise AssertionError("trial %r: %s" % ((trial, rpg, groups, S, cin, cout, pool, use_gb, relu), e))
+
+
+@pytest.mark.parametrize("chain", [True, False])
+def test_flipout_with_batch_norm_and_flipout_outputs(device, chain):
+    """The network of models/frustum_pointnet.py:108-295 - Flipout in EVERY layer, the two
+    output layers included, batch norm after every layer but the last (conv10 and fc3-stage1
+    too) - in fp32 on the chain kernels and on the per-layer kernels against the float64
+    estimator with the same noise, at the fp32 bar; the two paths agree with each other."""
+    import bf16_bounds as BB
+    from fpn import synthetic
+    from oracle import bayes_numpy as BN
+    B, N, S = 5, 128, 2
+    st, bp = BB.bayes_setup(device, 31, False, precision="fp32", full=True, chain=chain)
+    assert "fc3/rho" in st and "conv10/bn/gamma" in st and "fc3-stage1/bn/gamma" in st and "fc3/bn/gamma" not in st
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=32)
+    g = torch.Generator(device=device)
+    g.manual_seed(33)
+    noise = bp.sample_noise(S, B, g, N)
+    assert "fc3" in noise and "fc3-stage1" in noise
+    ep = bp.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+    params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
+    pc64, oh64 = pc.astype(np.float64), oh.astype(np.float64)
+    for s in range(S):
+        nz = BB.flipout_noise_of_sample(st, noise, s)
+        want = BN.forward_sample(pc64, oh64, params, nz, bn=True)
+        close(ep["mask_logits"][s].cpu().numpy(), want["mask_logits"], 1e-3)
+        mask = ep["mask"][s].cpu().numpy()
+        want = BN.forward_sample(pc64, oh64, params, nz, bn=True, mask_override=mask, recentre_box_input=False)
+        for k in ("center_delta", "stage1_center", "box_output", "center"):
+            close(ep[k][s].cpu().numpy(), want[k], 1e-3)
+    assert not torch.equal(ep["box_output"][0], ep["box_output"][1])
+    # batch norm matters: the same noise without the statistics gives other logits
+    plain = BN.forward_sample(pc64, oh64, params, BB.flipout_noise_of_sample(st, noise, 0), bn=False)
+    assert np.abs(plain["mask_logits"] - ep["mask_logits"][0].cpu().numpy()).max() > 1e-2
+
+
+def test_frustum_pointnet_module_builds_that_network(device):
+    """fpn.models.frustum_pointnet: constructor name, (train, detection) pair, eleven outputs, and
+    behind them the plan with batch norm and Flipout output layers."""
+    from fpn import synthetic, variables
+    from fpn.models import frustum_pointnet as FP
+    st = variables.VariableStore(device, seed=41)
+    with variables.use_store(st):
+        train, det = FP.frustum_pointnet()                  # default: 4-channel points, xyz + intensity
+        pc, oh = synthetic.make_frustums(4, 128, 4, seed=42)
+        labels = [np.zeros((4,) + s, np.float32) for s in ((3, 3), (128,), (3,), (), (), (), (3,))]
+        outs = det.predict([pc, oh] + labels, batch_size=4)
+        ep = FP.get_model(dev(pc, device), dev(oh, device), False)
+    assert len(outs) == len(FP.DETECTION_OUTPUTS) == 11
+    # outputs=[mask, logits, center, stage1_center, boxnet_center, ...] (frustum_pointnet.py:293-295)
+    assert outs[0].shape == (4, 128) and outs[1].shape == (4, 128, 2) and outs[2].shape == (4, 3)
+    np.testing.assert_allclose(outs[2], outs[3] + outs[4], rtol=1e-6, atol=1e-6)     # :253
+    assert "conv10/bn/moving_variance" in st and "fc3/rho" in st and st["conv1/weights"].shape == (4, 64)
+    assert ep["mask_logits"].shape == (4, 128, 2) and ep["center"].shape == (4, 3)
+
+
+def test_box_stack_on_unshifted_object_points(device):
+    """models/frustum_pointnet.py:214: the box stack's input is the gathered object points
+    without the T-net's shift.  Chain and per-layer paths, against the estimator with the
+    same option; the option changes the box output and nothing before it."""
+    import bf16_bounds as BB
+    from fpn import bayes, synthetic
+    from oracle import bayes_numpy as BN
+    B, N = 4, 128
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=52)
+    got = {}
+    for chain in (True, False):
+        st, _ = BB.bayes_setup(device, 51, False, precision="fp32", full=True, chain=chain)
+        bp = bayes.BayesPlan(st, 3, chain=chain, bn=True, flipout_outputs=True, recentre_box_input=False)
+        g = torch.Generator(device=device)
+        g.manual_seed(53)
+        noise = bp.sample_noise(1, B, g, N)
+        ep = bp.forward(dev(pc, device), dev(oh, device), 1, noise=noise)
+        params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
+        nz = BB.flipout_noise_of_sample(st, noise, 0)
+        mask = ep["mask"][0].cpu().numpy()
+        kw = dict(bn=True, mask_override=mask)
+        want = BN.forward_sample(pc.astype(np.float64), oh.astype(np.float64), params, nz, recentre_box_input=False, **kw)
+        other = BN.forward_sample(pc.astype(np.float64), oh.astype(np.float64), params, nz, **kw)
+        close(ep["box_output"][0].cpu().numpy(), want["box_output"], 1e-3)
+        close(ep["center"][0].cpu().numpy(), want["center"], 1e-3)
+        np.testing.assert_array_equal(want["center_delta"], other["center_delta"])
+        assert np.abs(want["box_output"] - other["box_output"]).max() > 1e-3
+        got[chain] = ep["box_output"][0].cpu().numpy()
+    close(got[True], got[False], 1e-3)

@@ -113,7 +113,7 @@ def _assert_bounds(name, model, exact):
     assert exact["mask_logits"] > 1e-5, "suspiciously exact: is the bf16 path running?"
 
 
-@pytest.mark.parametrize("case", ["v1", "flipout", "flipout_dropout"])
+@pytest.mark.parametrize("case", ["v1", "flipout", "flipout_dropout", "flipout_batch_norm"])
 def test_bf16_bounds_over_a_sweep_of_draws(device, case):
     """32 draws of weights (and batch-norm statistics / biases / Flipout noise / dropout bits)
     and inputs, 4 frustums x 256 points each: every output of every draw within MODEL_TOL of

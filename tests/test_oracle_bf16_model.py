@@ -109,3 +109,73 @@ def test_flipout_weights_of_the_model_are_the_textbook_estimator():
     got = Q.forward(pc, oh, Q.FlipoutWeights(params, noise))
     # integer arithmetic while values stay below 256; allow the rare larger activation its bf16 step
     np.testing.assert_allclose(got["mask_logits"], want["mask_logits"], rtol=2.0 ** -6, atol=1e-9)
+
+
+def _full_flipout_store(seed):
+    """Variables of the network of models/frustum_pointnet.py (batch norm everywhere but the
+    last layer, rho for every layer), batch-norm statistics random."""
+    from fpn import bayes, variables
+    st = variables.VariableStore(torch.device("cpu"), seed=seed)
+    bayes.init_variables(st, 3, bn=True, flipout_outputs=True)
+    st.randomize_batch_norm(seed + 1)
+    return st
+
+
+def _full_noise(rng, B, rho_scale, params):
+    from fpn import plan
+    from oracle import bayes_numpy as BN
+    noise = {}
+    for scope, cin, cout, _, _ in plan.layer_table(3):
+        sigma = np.log1p(np.exp(params[scope + "/rho"].astype(np.float64)))
+        noise[scope] = (rho_scale * sigma * rng.standard_normal((cin, cout)),
+                        rng.choice([-1.0, 1.0], (B, cin)), rng.choice([-1.0, 1.0], (B, cout)))
+    return noise
+
+
+def test_batch_norm_placement_of_the_flipout_estimator_is_the_v1_networks():
+    """With the perturbation at zero the Flipout + batch-norm estimator is a deterministic
+    network: the one of oracle/v1_numpy.py (pinned on its own fixtures) with batch norm,
+    except that it ALSO normalises conv10 and fc3-stage1 - give those two identity statistics
+    and the two must agree to float64 rounding."""
+    from oracle import bayes_numpy as BN
+    st = _full_flipout_store(11)
+    for scope in ("conv10", "fc3-stage1"):
+        n = st[scope + "/biases"].shape[0]
+        st[scope + "/bn/gamma"] = torch.ones(n)
+        st[scope + "/bn/beta"] = torch.zeros(n)
+        st[scope + "/bn/moving_mean"] = torch.zeros(n)
+        st[scope + "/bn/moving_variance"] = torch.full((n,), 1.0) - V.BN_EPS
+    params = {k: v.astype(np.float64) for k, v in st.numpy().items()}
+    for scope in ("conv10", "fc3-stage1"):
+        params[scope + "/bn/moving_variance"] = np.full_like(params[scope + "/bn/moving_variance"], 1.0 - V.BN_EPS)
+    from fpn import synthetic
+    pc, oh = synthetic.make_frustums(3, 64, 3, seed=12)
+    rng = np.random.RandomState(13)
+    noise = _full_noise(rng, 3, 0.0, params)
+    got = BN.forward_sample(pc.astype(np.float64), oh.astype(np.float64), params, noise, bn=True)
+    want = V.get_model(pc, oh, params, bn=True, dtype=np.float64)
+    np.testing.assert_allclose(got["mask_logits"], want["mask_logits"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(got["object_point_indices"], want["object_point_indices"])
+    np.testing.assert_allclose(got["center"], want["center"], rtol=1e-9, atol=1e-9)
+    # and the statistics of those two layers are used when they are not the identity
+    params["conv10/bn/gamma"] = params["conv10/bn/gamma"] * 2.0
+    twice = BN.forward_sample(pc.astype(np.float64), oh.astype(np.float64), params, noise, bn=True)
+    assert np.abs(twice["mask_logits"] - got["mask_logits"]).max() > 1e-3
+
+
+def test_rounding_model_of_flipout_with_batch_norm_within_the_stated_distance():
+    from fpn import synthetic
+    from oracle import bayes_numpy as BN
+    worst = {}
+    for seed in range(3):
+        st = _full_flipout_store(300 + seed)
+        params = st.numpy()
+        p64 = {k: v.astype(np.float64) for k, v in params.items()}
+        pc, oh = synthetic.make_frustums(3, 128, 3, seed=400 + seed)
+        noise = _full_noise(np.random.RandomState(500 + seed), 3, 1.0, p64)
+        model = Q.forward(pc, oh, Q.FlipoutWeights(params, noise, bn=True))
+        exact = BN.forward_sample(pc.astype(np.float64), oh.astype(np.float64), p64, noise, bn=True,
+                                  mask_override=model["mask"])
+        for k, m in model["summed_magnitude"].items():
+            worst[k] = max(worst.get(k, 0.0), BB.magnitude_error(model[k], exact[k], m))
+    assert 0.1 * BB.U < max(worst.values()) <= BB.EXACT_TOL, worst
