@@ -328,7 +328,7 @@ __device__ __forceinline__ void finish(Act &o, const floatx16 &a, const TileCons
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const int r = 8 * s + e;
-            const floatx2 y = floatx2{a[r], a[r + 1]} + floatx2{comp(sh.q[r >> 2], r & 3), comp(sh.q[r >> 2], (r & 3) + 1)};
+            const floatx2 y = {a[r] + comp(sh.q[r >> 2], r & 3), a[r + 1] + comp(sh.q[r >> 2], (r & 3) + 1)};
             const shortx2 v = __builtin_elementwise_max(__builtin_bit_cast(shortx2, __builtin_convertvector(y, bf16x2)),
                                                         shortx2{0, 0});
             bits[e] = v[0];

@@ -798,7 +798,7 @@ def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
 
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -831,12 +831,16 @@ def main():
                          "box vector + centres (no score without the logits)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a HIP graph (--config v2; removes the host launch overhead)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if args.stream_total and args.config != "v2":
         raise SystemExit("--stream-total goes with --config v2")
+    return args
 
+
+def main():
+    args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))         # this process never touches a GPU
     rank = int(os.environ.get("RANK", "0"))
