@@ -301,6 +301,19 @@ __device__ __forceinline__ bf16x8 *feed_ring()
     }
 }
 
+// (timing-only build, wrong results: every layer constant is read from LDS instead of memory - what the
+// kernels would gain if no constant load stood in the vector-memory queue between the weight loads)
+#ifdef FPN_CONST_LDS_TIMING
+__device__ __forceinline__ const float *const_src(const float *)
+{
+    __shared__ float dummy[2048];
+    dummy[(threadIdx.x * 8u + blockIdx.x) % 2048u] = 0.001f * threadIdx.x;      // (keeps the reads from folding to nothing)
+    return dummy;
+}
+#else
+__device__ __forceinline__ const float *const_src(const float *p) { return p; }
+#endif
+
 // per-channel constants of a lane for one 32-channel tile: channels ch0 + 8q + i
 struct TileConst {
     float4 q[4];
@@ -315,6 +328,22 @@ __device__ __forceinline__ void load_const(TileConst &c, const float *__restrict
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) c.q[q] = *reinterpret_cast<const float4 *>(p + ch0 + 8 * q);
+}
+
+// Layer constants of a wave, staged once in the wave's OWN piece of LDS (each wave reads only what it wrote:
+// no barrier).  Read from memory where a layer wants them, a constant stands in the wave's vector-memory queue
+// behind the weight units requested last - loads return in order, so waiting for it means waiting for the
+// whole read-ahead of the weight ring; LDS reads are counted apart from the weight loads.  N floats (a
+// multiple of 4), src 16-byte aligned.
+template <int N>
+__device__ __forceinline__ void stage_consts(float *dst, const float *__restrict__ src, unsigned lane)
+{
+    static_assert(N % 4 == 0, "whole 16-byte vectors");
+#pragma unroll
+    for (int i = 0; i < (N / 4 + 63) / 64; ++i) {
+        const int v = i * 64 + (int)lane;
+        if ((N / 4) % 64 == 0 || v < N / 4) reinterpret_cast<float4 *>(dst)[v] = reinterpret_cast<const float4 *>(src)[v];
+    }
 }
 
 // relu(acc + shift) as the next layer's operand, three instructions per register pair:
@@ -481,6 +510,7 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
     constexpr int U = NPAIR * NJ;
     floatx16 acc[2][2][NP];
     TileConst csh[2];
+    sh = const_src(sh);
     static_for<0, U>([&](auto I) {
         constexpr int S = decltype(I)::value, tp = S / NJ, j = S % NJ, set = tp & 1;
         constexpr int slot = (R0 + S) % Feed::kDepth;
@@ -658,6 +688,7 @@ __device__ __forceinline__ void layer_max(const Act (&in)[NP][NJ], const bf16x8 
         acc[1][1][g] = z;
     }
     float rsh[2] = {0.f, 0.f};
+    sh = const_src(sh);
 #pragma unroll 1
     for (int t0 = 0; t0 < NT; t0 += 4) {
         const bf16x8 *wt = ws + (size_t)(t0 / 2) * NJ * kUnitVecs;
@@ -828,6 +859,13 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
 
     Feed feed;
     feed.start(p.ws, lane, feed_ring<Feed>());
+    __shared__ float hconst[kWaves][64 + 64 + 128 + 1024];
+    float *lc = hconst[threadIdx.x >> 6];
+    stage_consts<64>(lc, p.sh2, lane);
+    stage_consts<64>(lc + 64, p.sh3, lane);
+    stage_consts<128>(lc + 128, p.sh4, lane);
+    stage_consts<1024>(lc + 256, p.sh5, lane);
+    const float *sh2 = lc, *sh3 = lc + 64, *sh4 = lc + 128, *sh5 = lc + 256;
     Act a1[NP][2], a2[NP][2], a3[NP][2], a4[NP][4];
     {
         FirstLayer<2, 8> first;
@@ -843,9 +881,9 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     }
     constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
     const bf16x8 *ws = p.ws;
-    layer_t<NP, 2, 2, 0>(a2, a1, ws, p.sh2, feed, h);
+    layer_t<NP, 2, 2, 0>(a2, a1, ws, sh2, feed, h);
     ws += U2 * kUnitVecs;
-    layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws, p.sh3, feed, h);
+    layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws, sh3, feed, h);
     ws += U3 * kUnitVecs;
 #pragma unroll
     for (int g = 0; g < NP; ++g)
@@ -853,13 +891,13 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h] = a3[g][t].m[s];
-    layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, p.sh4, feed, h);
+    layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, sh4, feed, h);
     ws += U4 * kUnitVecs;
     if (pool.on) {      // (two copies of the layer: LDS and memory atomics are different instructions)
-        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, lmax + pool.local * 1024, feed, lane);
+        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, sh5, lmax + pool.local * 1024, feed, lane);
         wg_pool_flush<1024>(lmax, pool, p.gmax, p.ldg, 1024);
     } else {
-        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, p.sh5, gmax, feed, lane);
+        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, sh5, gmax, feed, lane);
     }
 }
 
@@ -1034,7 +1072,10 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     // conv6's shifts - the frustum's row of 512 floats - wait in the wave's OWN piece of LDS (each wave reads only
     // what it wrote: no barrier) and come back one tile at a time, a unit or two before the epilogue that adds
     // them: 16 registers instead of 64 for two tiles held six units ahead of their use
-    __shared__ float shift6[kWaves][512];
+    // The other constants of the wave's layers wait there too (conv7's, conv8's and conv9's shifts, conv10's
+    // matrix, behind the 512 floats of conv6: see stage_consts; read from memory they cost 6 % of the kernel).
+    constexpr int kSh7 = 512, kSh8 = kSh7 + 256, kSh9 = kSh8 + 128, kW10 = kSh9 + 128, kTailConsts = kW10 + 256;
+    __shared__ float shift6[kWaves][kTailConsts];
     // two passes: the first pass's half of conv7's output (64 registers of operand fragments for two point
     // groups) has nothing to do during the second pass and waits in the wave's own piece of LDS as well
     // (vector v of a lane at [v][lane]: consecutive 16-byte slots, no bank conflicts) - held in registers it
@@ -1058,8 +1099,23 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     {
         const float4 *src = reinterpret_cast<const float4 *>(p.gshift + (row0 / p.n) * 512);   // (a wave's points lie in one frustum)
         const float4 lo = src[lane], hi = src[64 + lane];
+        const float4 c7 = reinterpret_cast<const float4 *>(p.sh7)[lane];
+        const float4 c89 = reinterpret_cast<const float4 *>(lane < 32 ? p.sh8 : p.sh9)[lane & 31];
+        const float4 c10 = reinterpret_cast<const float4 *>(p.w10)[lane];
         reinterpret_cast<float4 *>(sh6)[lane] = lo;
         reinterpret_cast<float4 *>(sh6)[64 + lane] = hi;
+        reinterpret_cast<float4 *>(sh6 + kSh7)[lane] = c7;
+        reinterpret_cast<float4 *>(sh6 + kSh8)[lane] = c89;         // (conv8's 128 shifts, then conv9's)
+        reinterpret_cast<float4 *>(sh6 + kW10)[lane] = c10;
+    }
+    const float *sh7 = sh6 + kSh7, *sh8 = sh6 + kSh8, *sh9 = sh6 + kSh9, *w10 = sh6 + kW10;
+    // ... and the points' dropout bits, wanted at the very end: requested there, they would be waited for
+    // with nothing left to compute
+    __shared__ uint4 keep_bits[kWaves][NP][64];
+    uint4 *keep_w = keep_bits[threadIdx.x >> 6][0];
+    if (p.drop) {
+#pragma unroll
+        for (int g = 0; g < NP; ++g) keep_w[g * 64 + lane] = *reinterpret_cast<const uint4 *>(p.drop + (row0 + 32 * g + pt) * 4);
     }
     Act pf[NP][2];
 #pragma unroll
@@ -1107,7 +1163,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
                 for (int tp = 0; tp < P; ++tp)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        load_const(c7, p.sh7, 32 * (2 * (w.pass * P + tp) + u) + 4 * h);
+                        load_const(c7, sh7, 32 * (2 * (w.pass * P + tp) + u) + 4 * h);
 #pragma unroll
                         for (int g = 0; g < NP; ++g) finish(a7[g][2 * (w.pass * P + tp) + u], acc7[tp][u][g], c7);
                     }
@@ -1136,16 +1192,16 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     ws += (size_t)Order::kStream * kUnitVecs;
     Act a8[NP][4];
     floatx16 a9[NP][4];
-    layer_t<NP, 8, 4, Order::kFused % Feed::kDepth>(a8, a7, ws, p.sh8, feed, h);
+    layer_t<NP, 8, 4, Order::kFused % Feed::kDepth>(a8, a7, ws, sh8, feed, h);
     ws += U8 * kUnitVecs;
-    layer_t<NP, 4, 4, (Order::kFused + U8) % Feed::kDepth>(a9, a8, ws, p.sh9, feed, h);
+    layer_t<NP, 4, 4, (Order::kFused + U8) % Feed::kDepth>(a9, a8, ws, sh9, feed, h);
 
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
         // Monte-Carlo dropout before the head (models/FPointNet_Bayes.py:92): bit c of word j
         // of the point's mask keeps channel 32 j + c, kept activations count twice
         if (p.drop) {
-            const uint4 keep = *reinterpret_cast<const uint4 *>(p.drop + (row0 + 32 * g + pt) * 4);
+            const uint4 keep = keep_w[g * 64 + lane];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned word = (j == 0 ? keep.x : j == 1 ? keep.y : j == 2 ? keep.z : keep.w) >> (4 * h);
@@ -1159,7 +1215,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 *w = reinterpret_cast<const float4 *>(p.w10 + (32 * j + 8 * q + 4 * h) * 2);
+                const float4 *w = reinterpret_cast<const float4 *>(w10 + (32 * j + 8 * q + 4 * h) * 2);
                 const float4 wa = w[0], wb = w[1];
                 s0 = fmaf(a9[g][j][4 * q + 0], wa.x, s0); s1 = fmaf(a9[g][j][4 * q + 0], wa.y, s1);
                 s0 = fmaf(a9[g][j][4 * q + 1], wa.z, s0); s1 = fmaf(a9[g][j][4 * q + 1], wa.w, s1);
@@ -1211,6 +1267,12 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
 
     Feed feed;
     feed.start(p.ws, lane, feed_ring<Feed>());
+    __shared__ float oconst[kWaves][128 + 256 + (BOX ? 512 : 0)];
+    float *lc = oconst[threadIdx.x >> 6];
+    stage_consts<128>(lc, p.sh2, lane);
+    stage_consts<256>(lc + 128, p.sh3, lane);
+    if constexpr (BOX) stage_consts<512>(lc + 384, p.sh4, lane);
+    const float *sh2 = lc, *sh3 = lc + 128, *sh4 = lc + 384;
     Act a1[NP][4], a2[NP][4];
     {
         FirstLayer<4, 4> first;
@@ -1227,17 +1289,17 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     }
     constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
     const bf16x8 *ws = p.ws;
-    layer_t<NP, 4, 4, 0>(a2, a1, ws, p.sh2, feed, h);
+    layer_t<NP, 4, 4, 0>(a2, a1, ws, sh2, feed, h);
     ws += U2 * kUnitVecs;
     if constexpr (!BOX) {
-        if (pool.on) layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, lmax + pool.local * C, feed, lane);
-        else layer_max<NP, 4, 8, U2 % kRing>(a2, ws, p.sh3, gmax, feed, lane);
+        if (pool.on) layer_max<NP, 4, 8, U2 % kRing>(a2, ws, sh3, lmax + pool.local * C, feed, lane);
+        else layer_max<NP, 4, 8, U2 % kRing>(a2, ws, sh3, gmax, feed, lane);
     } else {
         Act a3[NP][8];
-        layer_t<NP, 4, 8, U2 % kRing>(a3, a2, ws, p.sh3, feed, h);
+        layer_t<NP, 4, 8, U2 % kRing>(a3, a2, ws, sh3, feed, h);
         ws += U3 * kUnitVecs;
-        if (pool.on) layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, lmax + pool.local * C, feed, lane);
-        else layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, p.sh4, gmax, feed, lane);
+        if (pool.on) layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, sh4, lmax + pool.local * C, feed, lane);
+        else layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, sh4, gmax, feed, lane);
     }
     if (pool.on) wg_pool_flush<C>(lmax, pool, p.gmax, p.ldg, C);
 }
