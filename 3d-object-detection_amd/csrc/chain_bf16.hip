@@ -90,6 +90,32 @@ __device__ __forceinline__ void load_unit(WUnit &u, const bf16x8 *__restrict__ p
         for (int m = 0; m < 2; ++m) u.w[a][m] = p[(a * 2 + m) * 64 + lane];
 }
 
+// The same through a buffer descriptor: the lane's 16-byte slot is the instruction's vector offset (one
+// register for the whole kernel), the unit's position a scalar offset, the fragment an immediate - no vector
+// arithmetic per load.  (Read through per-lane pointers, every unit of an unrolled chain gets a 64-bit address
+// pair of its own; the compiler parks the pairs in accumulator registers and pays two moves per load - of the
+// seg head's 24 k cycles per round in conv5, 5 k were the weight loads' instructions.)
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+struct StreamWindow {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const bf16x8 *base;
+    __device__ __forceinline__ void bind(const bf16x8 *ws)
+    {
+        base = ws;
+        // (gfx9 raw buffer: 32-bit elements; the window is as long as an offset can be)
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(ws), 0, 0x7fffffff, 0x00020000);
+    }
+    __device__ __forceinline__ void load(WUnit &u, const bf16x8 *__restrict__ unit, unsigned lane) const
+    {
+        const int soff = (int)(reinterpret_cast<uintptr_t>(unit) - reinterpret_cast<uintptr_t>(base));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                u.w[a][m] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane * 16), soff + (a * 2 + m) * 1024, 0));
+    }
+};
+
 // Where a wave's weight units come from.  Both feeds hand out the unit of stream position
 // PH (mod 4) and are advanced once per unit, right after the unit's MFMAs are issued.
 //
@@ -124,11 +150,13 @@ struct RingFeedT {
     static constexpr int kMode = 0, kDepth = DEPTH;
     WUnit ring[DEPTH];
     unsigned lane;
+    StreamWindow win;
     __device__ __forceinline__ void start(const bf16x8 *__restrict__ ws, unsigned lane_, bf16x8 *)
     {
         lane = lane_;
+        win.bind(ws);
 #pragma unroll
-        for (int i = 0; i < DEPTH; ++i) load_unit(ring[i], ws + (size_t)i * kUnitVecs, lane);
+        for (int i = 0; i < DEPTH; ++i) win.load(ring[i], ws + (size_t)i * kUnitVecs, lane);
     }
     template <int PH>
     __device__ __forceinline__ const WUnit &cur() const { return ring[PH % DEPTH]; }
@@ -137,17 +165,19 @@ struct RingFeedT {
     // start_at(first(i)) = the unit consumed i-th, advance_at(next) = the unit consumed kLook
     // steps after the one being multiplied.
     static constexpr int kLook = DEPTH;
+    // (ws: the stream's first unit - no unit named later lies before it)
     template <class First>
-    __device__ __forceinline__ void start_at(First &&first, unsigned lane_, bf16x8 *)
+    __device__ __forceinline__ void start_at(First &&first, unsigned lane_, bf16x8 *, const bf16x8 *__restrict__ ws)
     {
         lane = lane_;
-        static_for<0, DEPTH>([&](auto I) { load_unit(ring[decltype(I)::value], first(I), lane); });
+        win.bind(ws);
+        static_for<0, DEPTH>([&](auto I) { win.load(ring[decltype(I)::value], first(I), lane); });
     }
     template <int PH>
     __device__ __forceinline__ void advance_at(const bf16x8 *__restrict__ next)
     {
 #ifndef FPN_RING_NOLOAD
-        load_unit(ring[PH % DEPTH], next, lane);
+        win.load(ring[PH % DEPTH], next, lane);
 #else       // timing-only build (wrong results): no loads; the fragments stay opaque so that every MFMA remains
         opaque(ring[PH % DEPTH]);
 #endif
@@ -162,6 +192,22 @@ struct RingFeedT {
     __device__ __forceinline__ void sync() {}
 };
 using RingFeed = RingFeedT<kRing>;
+
+// The ring of a kernel that walks its stream again and again (one round of points after another): past the
+// stream's last unit the read-ahead goes on at its first unit, so a round ends with the next round's first
+// units in the ring.  The stream's unit count must be a multiple of the ring's depth (the slot numbers come
+// round).  end = the first vector behind the last unit, len = the stream's length in vectors.
+template <int DEPTH>
+struct WrapRingFeedT : RingFeedT<DEPTH> {
+    const bf16x8 *end;
+    long len;
+    template <int PH>
+    __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
+    {
+        const bf16x8 *next = unit + (size_t)DEPTH * kUnitVecs;
+        this->template advance_at<PH>(next >= end ? next - len : next);
+    }
+};
 
 struct CoopFeed {
     static constexpr int kMode = 1, kDepth = 4;
@@ -205,7 +251,7 @@ struct CoopFeed {
     __device__ __forceinline__ const WUnit &cur() const { return frag[PH % 4]; }
     static constexpr int kLook = kFeedAhead + kFeedStage;
     template <class First>
-    __device__ __forceinline__ void start_at(First &&first, unsigned lane_, bf16x8 *ring)
+    __device__ __forceinline__ void start_at(First &&first, unsigned lane_, bf16x8 *ring, const bf16x8 *)
     {
         lane = lane_;
         lds = ring;
@@ -857,6 +903,13 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     if (pool.on) wg_pool_clear<1024>(lmax, pool);
     int *gmax = reinterpret_cast<int *>(p.gmax + (row0 / p.n) * p.ldg);
 
+#ifdef FPN_HEAD_STAMPS      // timing-only build: cycle stamps of one wave into the frustum's maxima row (wrong results)
+    long long stamp[8];
+    stamp[0] = clock64();
+#define FPN_HSTAMP(i) stamp[i] = clock64()
+#else
+#define FPN_HSTAMP(i)
+#endif
     Feed feed;
     feed.start(p.ws, lane, feed_ring<Feed>());
     __shared__ float hconst[kWaves][64 + 64 + 128 + 1024];
@@ -877,13 +930,17 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[g][k] = k < p.cpc ? src[k] : 0.f;
         }
+        FPN_HSTAMP(1);
         first.apply(a1, x, h);
     }
+    FPN_HSTAMP(2);
     constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
     const bf16x8 *ws = p.ws;
     layer_t<NP, 2, 2, 0>(a2, a1, ws, sh2, feed, h);
+    FPN_HSTAMP(3);
     ws += U2 * kUnitVecs;
     layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws, sh3, feed, h);
+    FPN_HSTAMP(4);
     ws += U3 * kUnitVecs;
 #pragma unroll
     for (int g = 0; g < NP; ++g)
@@ -892,13 +949,136 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
 #pragma unroll
             for (int s = 0; s < 2; ++s) p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h] = a3[g][t].m[s];
     layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, sh4, feed, h);
+    FPN_HSTAMP(5);
     ws += U4 * kUnitVecs;
     if (pool.on) {      // (two copies of the layer: LDS and memory atomics are different instructions)
         layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, sh5, lmax + pool.local * 1024, feed, lane);
+        FPN_HSTAMP(6);
         wg_pool_flush<1024>(lmax, pool, p.gmax, p.ldg, 1024);
+#ifdef FPN_HEAD_STAMPS
+        stamp[7] = clock64();
+        if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
+            for (int i = 0; i < 8; ++i) reinterpret_cast<long long *>(p.gmax)[32 + i] = stamp[i];
+#endif
     } else {
         layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws, sh5, gmax, feed, lane);
     }
+}
+
+// ---------------------------------------------------------------------------
+// seg head, a WORKGROUP PER FRUSTUM.  seg_head_bf16_kernel's waves live for one round of 32 NP points: of a
+// wave's 36 k cycles 6.6 k pass before its first MFMA (parameters, first-layer weights, the points and the
+// first weight units all come from memory, and with one wave per SIMD nothing else runs meanwhile), and conv4
+// waits 2.7 k for the point_feat stores in front of its weight loads (stores and loads complete in order).
+// Here a workgroup takes a whole frustum: its points come into LDS in one sweep, the first layer's operands,
+// the layer constants and the ring are set up once, and the waves then walk the frustum in rounds of
+// kWaves x 32 NP points - the ring wraps (WrapRingFeedT), so a round starts with its first units loaded; a
+// round's point_feat stores go out behind its last layer, where only the next round's first waits see them;
+// the maxima of all rounds meet in LDS and leave with one atomic per channel.  Same arithmetic per point
+// as seg_head_bf16_kernel: same bits.  Needs n % (kWaves * 32 NP) == 0 and n * cpc <= kHeadXin floats.
+// ---------------------------------------------------------------------------
+constexpr int kHeadXin = 8192;
+
+template <int NP, class Feed>
+__global__ __launch_bounds__(64 * kWaves) void seg_head_frustum_bf16_kernel(const HeadParams pin)
+{
+    constexpr int kRound = kWaves * 32 * NP;
+    constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128), U5 = units_of(128, 1024);
+    static_assert((U2 + U3 + U4 + U5) % kRing == 0, "the ring's slots must come round with the stream");
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const long f = logical_block(pin.copy_vecs);
+    HeadParams p = pin;
+    if (pin.copy_vecs) {
+        p.ws += (size_t)f * pin.copy_vecs;
+        p.w1 += (size_t)f * (size_t)(pin.cpc * 64);
+    }
+    __shared__ int lmax[1024];
+    __shared__ float hconst[64 + 64 + 128 + 1024];
+    __shared__ float xin[kHeadXin];
+
+#ifdef FPN_HEAD_STAMPS
+    long long stamp[12];
+    stamp[0] = clock64();
+#endif
+    Feed feed;
+    feed.start(p.ws, lane, feed_ring<Feed>());
+    feed.end = p.ws + (size_t)(U2 + U3 + U4 + U5) * kUnitVecs;
+    feed.len = (long)(U2 + U3 + U4 + U5) * kUnitVecs;
+    FirstLayer<2, 8> first;
+    first.load(p.w1, p.cpc, p.sc1, p.sh1, lane, h);
+    {
+        const int vecs = p.n * p.cpc / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(p.pc + (size_t)f * p.n * p.cpc);
+        for (int i = threadIdx.x; i < vecs; i += 64 * kWaves) reinterpret_cast<float4 *>(xin)[i] = src[i];
+        for (int i = threadIdx.x; i < 1024; i += 64 * kWaves) lmax[i] = 0;
+        if (wave == 0) {
+            stage_consts<64>(hconst, p.sh2, lane);
+            stage_consts<64>(hconst + 64, p.sh3, lane);
+        } else if (wave == 1) {
+            stage_consts<128>(hconst + 128, p.sh4, lane);
+        } else {
+            stage_consts<512>(hconst + 256 + 512 * (wave - 2), p.sh5 + 512 * (wave - 2), lane);
+        }
+    }
+    __syncthreads();
+    const float *sh2 = hconst, *sh3 = hconst + 64, *sh4 = hconst + 128, *sh5 = hconst + 256;
+    const bf16x8 *ws = p.ws;
+
+#pragma unroll 1
+    for (int r0 = (int)wave * (32 * NP); r0 < p.n; r0 += kRound) {
+#ifdef FPN_HEAD_STAMPS
+        const bool st = r0 / kRound == 1;
+        if (r0 / kRound == 0) stamp[1] = clock64();
+        if (st) stamp[2] = clock64();
+#define FPN_FSTAMP(i) if (st) stamp[i] = clock64()
+#else
+#define FPN_FSTAMP(i)
+#endif
+        Act a1[NP][2], a2[NP][2], a3[NP][2], a4[NP][4];
+        {
+            float x[NP][8];
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                const float *src = xin + (r0 + 32 * g + pt) * p.cpc;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[g][k] = k < p.cpc ? src[k] : 0.f;
+            }
+            first.apply(a1, x, h);
+        }
+        FPN_FSTAMP(3);
+        layer_t<NP, 2, 2, 0>(a2, a1, ws, sh2, feed, h);
+        FPN_FSTAMP(4);
+        layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws + U2 * kUnitVecs, sh3, feed, h);
+        FPN_FSTAMP(5);
+        const long row0 = f * p.n + r0;
+        auto store_feat = [&]() {       // point_feat = conv3's output
+#pragma unroll
+            for (int g = 0; g < NP; ++g)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s2) * 2 + h] = a3[g][t].m[s2];
+        };
+        layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws + (U2 + U3) * kUnitVecs, sh4, feed, h);
+        FPN_FSTAMP(6);
+        layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws + (U2 + U3 + U4) * kUnitVecs, sh5, lmax, feed, lane);
+        FPN_FSTAMP(7);
+        store_feat();     // (behind the last layer: only the next round's first waits stand behind these stores)
+        FPN_FSTAMP(8);
+    }
+#ifdef FPN_HEAD_STAMPS
+    stamp[9] = clock64();
+#endif
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < 1024; ch += 64 * kWaves)
+        atomicMax(reinterpret_cast<int *>(p.gmax + f * p.ldg + ch), lmax[ch]);
+#ifdef FPN_HEAD_STAMPS
+    stamp[10] = clock64();
+    if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
+        for (int i = 0; i < 11; ++i) reinterpret_cast<long long *>(pin.gmax)[32 + i] = stamp[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1092,7 +1272,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     }
     const bf16x8 *ws = p.ws;
     Feed feed;
-    feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, feed_ring<Feed>());
+    feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, feed_ring<Feed>(), ws);
     bf16x8 *park = park7 + (kPark ? (threadIdx.x >> 6) * (kParkVecs * 64) + lane : 0);
 
     float *sh6 = shift6[threadIdx.x >> 6];
@@ -2272,6 +2452,21 @@ int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void 
     p.copy_vecs = copy_vecs;
     // (the cooperative feed was measured here too: 0.43 -> 0.41 ms with one stream per frustum copy, nothing
     // with a shared stream: two point groups per wave already use every fragment twice)
+    // FPN_BF16_HEAD: "round" = a wave per round of points (any shape), "frustum" = a workgroup per frustum where
+    // the shape allows; default: per frustum once there is a frustum for every CU
+    const char *form = std::getenv("FPN_BF16_HEAD");
+    const std::string hf = form ? form : "";
+    const long frustums = rows / n;
+    const bool fits = n % (kWaves * 64) == 0 && (long)n * cpc <= kHeadXin && (reinterpret_cast<uintptr_t>(pc) & 15) == 0;
+    const int cus = current_device_cus();
+    if (fits && hf != "round" && (hf == "frustum" || (cus > 0 && frustums >= cus))) {
+        // (the workgroup's LDS ring as the feed - every unit once through the vector memory path - measured here
+        // too: conv5 24.9 k cycles a round against 24.1 k)
+        // (four point groups per wave - every fragment used four times - fill the register file: conv5's two
+        // accumulator sets 256, its input 128, the ring 64; the compiler spilled inside the loop: 0.48 ms against 0.24)
+        hipLaunchKernelGGL((seg_head_frustum_bf16_kernel<2, WrapRingFeedT<kRing>>), dim3((unsigned)frustums), dim3(64 * kWaves), 0, as_stream(stream), p);
+        return check_launch("fpn_v1_seg_head_bf16");
+    }
     if (groups_per_wave(n) == 2)
         hipLaunchKernelGGL(seg_head_bf16_kernel<2>, grid_for(rows, 2), dim3(64 * kWaves), 0, as_stream(stream), p);
     else

@@ -299,6 +299,47 @@ def test_bf16_tail_forms_agree_bit_for_bit(device, monkeypatch, B, N, dropout):
         assert torch.equal(res, got["layers", "ring"]), key
 
 
+@pytest.mark.parametrize("B,N,C", [(5, 256, 4), (3, 1024, 3), (2, 2048, 4), (8, 512, 8)])
+def test_bf16_head_forms_agree_bit_for_bit(device, monkeypatch, B, N, C):
+    """The seg head with a workgroup per frustum (points in LDS, rounds over a wrapping weight
+    ring, maxima merged in LDS) against the kernel whose waves take one round each: the same
+    arithmetic per point, so point_feat and the frustum maxima are the same bits; shared
+    stream and one stream per frustum copy."""
+    from fpn import bayes, ops, plan, synthetic, variables
+    st = variables.VariableStore(device, seed=14)
+    plan.init_variables(st, C, True)
+    st.randomize_batch_norm(15)
+    net = plan.V1Plan(st, C, True, precision="bf16")
+    pc, _ = synthetic.make_frustums(B, N, C, seed=B + N)
+    x = dev(pc, device).reshape(B * N, C)
+    got = {}
+    for form in ("round", "frustum"):
+        monkeypatch.setenv("FPN_BF16_HEAD", form)
+        point_feat = torch.zeros((B * N, 64), dtype=torch.bfloat16, device=device)
+        gcat = torch.zeros((B, 1024 + 3), device=device)
+        ops.v1_seg_head_bf16(x, N, net._head_ws, net._head_consts, point_feat, gcat)
+        got[form] = (point_feat, gcat)
+    assert float(got["round"][1].abs().max()) > 0 and float(got["round"][0].float().abs().max()) > 0
+    assert torch.equal(got["round"][0], got["frustum"][0])
+    assert torch.equal(got["round"][1], got["frustum"][1])
+    if C != 3:
+        return
+    # Flipout: per-copy streams through the whole plan
+    st = variables.VariableStore(device, seed=16)
+    bp = bayes.BayesPlan(st, 3, precision="bf16")
+    pc, oh = synthetic.make_frustums(B, N, 3, seed=17)
+    g = torch.Generator(device=device)
+    g.manual_seed(18)
+    noise = bp.sample_noise(2, B, g, N)
+    res = {}
+    for form in ("round", "frustum"):
+        monkeypatch.setenv("FPN_BF16_HEAD", form)
+        ep = bp.forward(dev(pc, device), dev(oh, device), 2, noise=noise)
+        res[form] = {k: ep[k].clone() for k in ("mask_logits", "box_output")}
+    for k in res["round"]:
+        assert torch.equal(res["round"][k], res["frustum"][k]), k
+
+
 @pytest.mark.parametrize("rows,cin,cout,pool,gb", [
     (300, 67, 59, 0, 0), (4096, 448, 128, 0, 0), (1024, 643, 200, 32, 0), (2048, 256, 1024, 64, 0),
     (1536, 128, 256, 128, 0), (2048, 640, 128, 0, 256), (4096, 256, 512, 512, 0), (640, 130, 128, 0, 5),

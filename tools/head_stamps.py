@@ -1,0 +1,33 @@
+"""Cycle stamps of one wave of the bf16 seg head (a library built with -DFPN_HEAD_STAMPS, named by
+FPN_LIB_PATH): where a wave's time goes, layer by layer.   python tools/head_stamps.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-object-detection_amd")]
+import torch  # noqa: E402
+
+from fpn import ops, plan, synthetic, variables  # noqa: E402
+
+dev = torch.device("cuda:0")
+b, n = 1024, 1024
+st = variables.VariableStore(dev, seed=1)
+plan.init_variables(st, 4, True)
+st.randomize_batch_norm(2)
+net = plan.V1Plan(st, 4, True, precision="bf16")
+pc, _ = synthetic.make_frustums(b, n, 4, seed=0)
+x = torch.from_numpy(pc).to(dev).reshape(b * n, 4)
+point_feat = torch.empty((b * n, 64), dtype=torch.bfloat16, device=dev)
+frustum = os.environ.get("FPN_BF16_HEAD", "frustum") != "round"
+names = ["setup", "round 0", "inputs", "conv1", "conv2", "conv3", "conv4", "conv5", "stores", "rounds 2..", "flush"] if frustum else \
+    ["start+issue", "inputs", "conv1", "conv2", "conv3+store", "conv4", "conv5", "flush"]
+if frustum:
+    names = ["", "setup", "round 0", "x from LDS", "conv1", "conv2", "conv3", "conv4", "conv5", "stores -> loop end", "flush"]
+for rep in range(4):
+    gcat = torch.zeros((b, 1024 + 3), device=dev)
+    ops.v1_seg_head_bf16(x, n, net._head_ws, net._head_consts, point_feat, gcat)
+    torch.cuda.synchronize()
+    cnt = 11 if frustum else 8
+    raw = gcat.reshape(-1)[:128].cpu().view(torch.int64)[32:32 + cnt].tolist()
+    d = [raw[i + 1] - raw[i] for i in range(cnt - 1)]
+    print("total %6d  " % (raw[cnt - 1] - raw[0]) + "  ".join("%s %d" % (nm, v) for nm, v in zip(names[1:], d)))
