@@ -403,7 +403,11 @@ __device__ __forceinline__ void finish(Act &o, const floatx16 &a, const TileCons
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const int r = 8 * s + e;
+#ifdef FPN_NOADD_TIMING     // (timing-only build, wrong results: what the epilogues' shift additions cost)
+            const floatx2 y = {a[r], a[r + 1]};
+#else
             const floatx2 y = {a[r] + comp(sh.q[r >> 2], r & 3), a[r + 1] + comp(sh.q[r >> 2], (r & 3) + 1)};
+#endif
             const shortx2 v = __builtin_elementwise_max(__builtin_bit_cast(shortx2, __builtin_convertvector(y, bf16x2)),
                                                         shortx2{0, 0});
             bits[e] = v[0];
@@ -2288,6 +2292,9 @@ inline bool use_coop(long rows, int np, long copy_vecs, long group)
     return coop_feed() && rows % wg_rows == 0 && (copy_vecs == 0 || group % wg_rows == 0);
 }
 
+// the kernels copy their layer constants with 16-byte loads (stage_consts, load_const)
+inline bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
 inline dim3 grid_for(long rows, int np)
 {
     const long waves = rows / (32 * np);
@@ -2442,7 +2449,9 @@ int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void 
     FPN_REQUIRE(ldg >= 1024, "v1_seg_head_bf16: leading dimension of global_max (%d) must be >= 1024", ldg);
     if (rows == 0) return FPN_OK;
     FPN_REQUIRE(pc && wstream && consts && point_feat && global_max, "v1_seg_head_bf16: null pointer");
-    for (int i = 0; i < 7; ++i) FPN_REQUIRE(consts[i], "v1_seg_head_bf16: constant %d is null", i);
+    for (int i = 0; i < 7; ++i)
+        FPN_REQUIRE(consts[i] && aligned16(consts[i]), "v1_seg_head_bf16: constant %d is null or not 16-byte aligned", i);
+    FPN_REQUIRE(aligned16(wstream), "v1_seg_head_bf16: the weight stream must be 16-byte aligned");
     HeadParams p{};
     p.rows = rows; p.n = n; p.cpc = cpc; p.pc = pc;
     p.w1 = consts[0]; p.sc1 = consts[1]; p.sh1 = consts[2];
@@ -2483,7 +2492,11 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
     FPN_REQUIRE(n % 32 == 0 && rows % n == 0, "v1_seg_tail_bf16: points per frustum (%d) must be a multiple of 32", n);
     if (rows == 0) return FPN_OK;
     FPN_REQUIRE(point_feat && group_shift && wstream && consts && logits, "v1_seg_tail_bf16: null pointer");
-    for (int i = 0; i < 5; ++i) FPN_REQUIRE(consts[i], "v1_seg_tail_bf16: constant %d is null", i);
+    for (int i = 0; i < 4; ++i)
+        FPN_REQUIRE(consts[i] && aligned16(consts[i]), "v1_seg_tail_bf16: constant %d is null or not 16-byte aligned", i);
+    FPN_REQUIRE(consts[4], "v1_seg_tail_bf16: constant 4 is null");
+    FPN_REQUIRE(aligned16(wstream) && aligned16(group_shift) && aligned16(point_feat),
+                "v1_seg_tail_bf16: point_feat, group_shift and the weight stream must be 16-byte aligned");
     TailParams p{};
     p.rows = rows; p.n = n; p.point_feat = reinterpret_cast<const bf16x8 *>(point_feat); p.gshift = group_shift;
     p.ws = reinterpret_cast<const bf16x8 *>(wstream);
@@ -2528,7 +2541,9 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
     if (rows == 0) return FPN_OK;
     FPN_REQUIRE(obj && wstream && consts && feat_max, "v1_obj_chain_bf16: null pointer");
     const int nc = box ? 6 : 5;
-    for (int i = 0; i < nc; ++i) FPN_REQUIRE(consts[i], "v1_obj_chain_bf16: constant %d is null", i);
+    for (int i = 0; i < nc; ++i)
+        FPN_REQUIRE(consts[i] && aligned16(consts[i]), "v1_obj_chain_bf16: constant %d is null or not 16-byte aligned", i);
+    FPN_REQUIRE(aligned16(wstream), "v1_obj_chain_bf16: the weight stream must be 16-byte aligned");
     ObjParams p{};
     p.rows = rows; p.m = m; p.obj = obj; p.delta = delta;
     p.w1 = consts[0]; p.sc1 = consts[1]; p.sh1 = consts[2];
