@@ -502,6 +502,15 @@ def pointset_ops(dev, frustums=256, reps=20):
     fps["algorithmic_lane_ops_per_frustum"] = lane_ops
     fps["achieved_Tlaneops"] = B * lane_ops / fps["ms"] / 1e9
     fps["frac_of_valu_peak"] = fps["achieved_Tlaneops"] / (256 * 128 * 2.4e9 / 1e12)
+    # three_nn is bound the same way: every (query, known point) pair costs the squared distance
+    # (8 operations, rounded one by one) and the reference's strict-"<" insertion into the three
+    # running bests with their indices (3 comparisons, 10 selects): 21 lane operations a pair.
+    for key in ("three_nn(2048,128)", "three_nn_interpolate(2048,128,c=64)"):
+        if key in out:
+            row = out[key]
+            row["algorithmic_lane_ops_per_frustum"] = 21.0 * N * M
+            row["achieved_Tlaneops"] = B * 21.0 * N * M / row["ms"] / 1e9
+            row["frac_of_valu_peak"] = row["achieved_Tlaneops"] / (256 * 128 * 2.4e9 / 1e12)
     return out
 
 
