@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
-bash tools/run_counters.sh r03_c_v1 v1_f32_1024x1024 --no-pointset --steps 10 --warmup 3 > gpurun_out/r03_c_v1.log 2>&1
+bash tools/run_counters.sh r03_c_v1 v1_f32_1024x1024 --no-pointset --no-side-workloads --steps 10 --warmup 3 > gpurun_out/r03_c_v1.log 2>&1
 echo v1 done
 bash tools/run_counters.sh r03_c_v1_bf16 v1_bf16_1024x1024 --no-pointset --dtype bf16 --steps 10 --warmup 3 > gpurun_out/r03_c_v1_bf16.log 2>&1
 echo v1bf16 done
