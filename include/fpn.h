@@ -490,7 +490,9 @@ int fpn_fp_head_chain_pre_f32(long rows, int cb, const float *pre, const float *
  * layers of a kernel back to back (the order is given with each entry point) and
  * leaves fpn_chain_pad_units_bf16() * 4096 bytes of readable padding after the last
  * one (the kernels read ahead).  cin % 32 == 0, cout % 64 == 0.
- *   `consts`: HOST array of device pointers to the fp32 per-channel constants.
+ *   `consts`: HOST array of device pointers to the fp32 per-channel constants.  The
+ * streams and every constant array must be 16-byte aligned (they are read as 16-byte
+ * vectors); a stream or a copy's stream must be shorter than 2 GiB.
  */
 int fpn_chain_pad_units_bf16(void);
 int fpn_chain_pack_bf16(int cin, int cout, const float *w, const float *scale, void *units,
