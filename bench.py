@@ -290,6 +290,39 @@ def measured_traffic(obs_name, workload):
     return None, None
 
 
+def recorded_clock(obs_name, workload):
+    """The clock the chip held under the kernel behind `obs_name`, from the newest committed
+    counter record of this workload: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the
+    kernel's average duration in the kernel trace of the same command (profiles/*_sq.json and
+    *_kernel_stats.csv, tools/run_counters.sh).  Dense bf16 MFMA loops on random data run well
+    below the 2.4 GHz the peak is quoted at; (None, None) when no record holds the kernel."""
+    import csv
+    import glob
+    prefix = pmc_kernel_prefix(obs_name)
+    if prefix is None or workload is None:
+        return None, None
+    prefixes = prefix if isinstance(prefix, tuple) else (prefix,)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("workload") != workload:
+                continue
+            stats = path[:-len("sq.json")] + "kernel_stats.csv"
+            with open(stats) as f:
+                rows = list(csv.DictReader(f))
+        except (OSError, ValueError):
+            continue
+        for k, v in d["kernels"].items():
+            name = k.split(" @ ")[0]
+            if not name.startswith(prefixes) or "GRBM_GUI_ACTIVE" not in v.get("counters", {}):
+                continue
+            for r in rows:       # the same instantiation of the kernel in the trace
+                if name in r["Name"].replace("fpn::(anonymous namespace)::", "") and float(r["AverageNs"]) > 0:
+                    return v["counters"]["GRBM_GUI_ACTIVE"] / 8.0 / float(r["AverageNs"]), os.path.basename(path)
+    return None, None
+
+
 # ---- CPU baselines (the oracle, timed on this host) ------------------------------------
 
 def cpu_info():
@@ -789,6 +822,12 @@ def measure(args, dev, rank, world, extras=True, cpu_seconds=8.0):
                                "launches": launches, "avg_launch_ms": secs / launches * 1e3,
                                "algorithmic_gflop_per_launch": flops / launches / 1e9,
                                "share_of_step_time": secs / dt}
+            # the peak is quoted at 2.4 GHz; the clock the chip held under this kernel when its
+            # counters were recorded (frac itself stays against the nominal peak)
+            ghz, ghz_src = recorded_clock(dominant, wl["workload_tag"])
+            if ghz:
+                out["roofline"].update({"recorded_clock_ghz": ghz, "clock_source": ghz_src,
+                                        "frac_of_peak_at_recorded_clock": ach / (peak * ghz / 2.4)})
             out["kernels"] = {k: {"launches": v[0], "gflop": v[1] / 1e9, "ms": v[2] * 1e3,
                                   "ms_fastest_step": v[3] * 1e3,
                                   "tflops": v[1] / v[2] / 1e12 if v[2] > 0 else None} for k, v in full.items()}

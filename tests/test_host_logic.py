@@ -203,3 +203,22 @@ def test_synthetic_frustums():
     assert np.array_equal(np.concatenate([p[1] for p in parts]), oh_w)
     assert (oh_w.argmax(1) == np.arange(10) % 3).all() and not np.array_equal(whole[0], whole[3])
     assert synthetic.make_frustums_range(4, 4, 64)[0].shape == (0, 64, 4)
+
+
+def test_bench_reads_its_recorded_counters():
+    """bench.py's roofline carries two recorded measurements next to the live timing: HBM
+    bytes per launch and the clock the chip held, both looked up in profiles/ by workload and
+    kernel.  The committed records must be found for the headline and the bf16 workloads, and
+    say what they are known to say (fp32 chains near 2.4 GHz, bf16 chains well below it;
+    the fp32 tail's traffic close to its 279 MB of algorithmic bytes)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    ghz, src = bench.recorded_clock("v1_seg_tail", "v1_f32_1024x1024")
+    assert src and 2.2 < ghz < 2.45, (ghz, src)
+    ghz16, src16 = bench.recorded_clock("v1_seg_tail_bf16", "v1_bf16_1024x1024")
+    assert src16 and 1.5 < ghz16 < ghz, (ghz16, src16)
+    traffic, tsrc = bench.measured_traffic("v1_seg_tail", "v1_f32_1024x1024")
+    assert tsrc and 0.9 * 279e6 < traffic < 1.5 * 279e6, (traffic, tsrc)
+    assert bench.recorded_clock("v1_seg_tail", "no_such_workload") == (None, None)
