@@ -19,10 +19,9 @@ pc, _ = synthetic.make_frustums(b, n, 4, seed=0)
 x = torch.from_numpy(pc).to(dev).reshape(b * n, 4)
 point_feat = torch.empty((b * n, 64), dtype=torch.bfloat16, device=dev)
 frustum = os.environ.get("FPN_BF16_HEAD", "frustum") != "round"
-names = ["setup", "round 0", "inputs", "conv1", "conv2", "conv3", "conv4", "conv5", "stores", "rounds 2..", "flush"] if frustum else \
-    ["start+issue", "inputs", "conv1", "conv2", "conv3+store", "conv4", "conv5", "flush"]
-if frustum:
-    names = ["", "setup", "round 0", "x from LDS", "conv1", "conv2", "conv3", "conv4", "conv5", "stores -> loop end", "flush"]
+# differences of consecutive stamps
+names = ["set-up", "round 0", "round 1: inputs + conv1", "conv2", "conv3", "conv4", "conv5", "stores", "rounds 2..", "flush"] \
+    if frustum else ["start + issue", "inputs", "conv1", "conv2", "conv3 + store", "conv4", "conv5 (+ flush)"]
 for rep in range(4):
     gcat = torch.zeros((b, 1024 + 3), device=dev)
     ops.v1_seg_head_bf16(x, n, net._head_ws, net._head_consts, point_feat, gcat)
@@ -30,4 +29,4 @@ for rep in range(4):
     cnt = 11 if frustum else 8
     raw = gcat.reshape(-1)[:128].cpu().view(torch.int64)[32:32 + cnt].tolist()
     d = [raw[i + 1] - raw[i] for i in range(cnt - 1)]
-    print("total %6d  " % (raw[cnt - 1] - raw[0]) + "  ".join("%s %d" % (nm, v) for nm, v in zip(names[1:], d)))
+    print("total %6d  " % (raw[cnt - 1] - raw[0]) + "  ".join("%s %d" % (nm, v) for nm, v in zip(names, d)))
