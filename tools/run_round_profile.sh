@@ -11,13 +11,14 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python -u bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-args="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pointset --no-kernel-timer --steps 5 --warmup 2"
-# (40 steps: the first launches after start-up run at ramping clocks and would dominate a short average)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o v1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pointset --no-kernel-timer --steps 40 --warmup 5 > $out/stats_run.log 2>&1
+args="$GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pointset --no-kernel-timer --no-side-workloads --steps 5 --warmup 2"
+# (40 steps: the first launches after start-up run at ramping clocks and would dominate a short average;
+# the headline workload alone: the side workloads launch the same kernels with per-copy weights)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o v1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pointset --no-kernel-timer --no-side-workloads --steps 40 --warmup 5 > $out/stats_run.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $args > $out/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $args > $out/pmc_write.log 2>&1
 cd $GRAFT_REPO_ROOT
-python tools/pmc_summary.py $out/pmc_fetch $out/pmc_write > $out/pmc_traffic.json
+python tools/pmc_summary.py $out/pmc_fetch $out/pmc_write --workload v1_f32_1024x1024 > $out/pmc_traffic.json
 head -c 700 $out/bench.json; echo
 head -8 $(find $out/stats -name "*kernel_stats.csv" | head -1) | cut -c1-170
 head -c 1500 $out/pmc_traffic.json
