@@ -82,6 +82,17 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.fpn_fp_head_chain_pre_f32(48, 4, P, P, P, P, None) == -1
     assert lib.fpn_fp_head_chain_pre_bf16(64, 9, P, P, P, P, P, None) == -1
     assert lib.fpn_fp_head_chain_pre_bf16(0, 4, None, None, None, None, None, None) == 0
+    # the bf16 chains read their streams and constants as 16-byte vectors: a misaligned array is refused
+    good = (ctypes.c_void_p * 7)(*([256] * 7))
+    bad = (ctypes.c_void_p * 7)(*([256, 256, 256, 260, 256, 256, 256]))
+    assert lib.fpn_v1_seg_head_bf16(64, 32, 4, P, P, bad, 0, P, P, 1024, None) == -1
+    assert b"16-byte aligned" in lib.fpn_last_error_string()
+    assert lib.fpn_v1_seg_head_bf16(64, 32, 4, P, ctypes.c_void_p(24), good, 0, P, P, 1024, None) == -1
+    assert lib.fpn_v1_seg_tail_bf16(64, 32, P, P, P, bad, 0, None, P, None) == -1
+    assert lib.fpn_v1_seg_tail_bf16(64, 32, P, ctypes.c_void_p(20), P, good, 0, None, P, None) == -1
+    assert lib.fpn_v1_obj_chain_bf16(64, 32, 1, P, None, P, bad, 0, P, 512, None) == -1
+    assert b"16-byte aligned" in lib.fpn_last_error_string()
+    assert lib.fpn_v1_seg_head_bf16(0, 32, 4, None, None, None, 0, None, None, 1024, None) == 0
 
 
 def test_ball_threshold_equals_sqrt_test():
