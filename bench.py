@@ -906,8 +906,9 @@ def main():
             # same protocol (fewer steps): each is a complete report of its own under its key
             import copy
             out["side_workloads"] = {}
-            for key, config, dtype, steps in (("v2_f32", "v2", "f32", 10), ("v2_bf16", "v2", "bf16", 10),
-                                              ("bayes_f32", "bayes", "f32", 3), ("bayes_bf16", "bayes", "bf16", 3)):
+            for key, config, dtype, steps in (("v1_bf16", "v1", "bf16", 20), ("v2_f32", "v2", "f32", 10),
+                                              ("v2_bf16", "v2", "bf16", 10), ("bayes_f32", "bayes", "f32", 3),
+                                              ("bayes_bf16", "bayes", "bf16", 3)):
                 side = copy.copy(args)
                 side.config, side.dtype, side.steps, side.warmup = config, dtype, steps, 2
                 side.no_pointset = True
