@@ -21,16 +21,25 @@ __constant__ double kMeanSize[NS][3] = {
     {0.80057803, 0.5983815, 1.27450867},          {1.76282397, 0.59706367, 1.73698127},
     {16.17150617, 2.53246914, 3.53079012},        {3.64300781, 1.54298177, 1.92320313}};
 
-__global__ void mc_statistics_kernel(int s, int b, const float *__restrict__ box, const float *__restrict__ c1,
-                                     float *__restrict__ stats)
+// One wave per frustum: lane t takes samples t, t + 64, ... (a sample's twenty exponentials are in double
+// precision: one thread per frustum walking 32 samples took 0.1 ms for 128 frustums, two waves on the whole
+// chip), the lanes' partial sums meet in a butterfly of fixed order - the result does not depend on timing.
+__device__ __forceinline__ double wave_sum(double v)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= b) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void mc_statistics_kernel(int s, int b, const float *__restrict__ box,
+                                                           const float *__restrict__ c1, float *__restrict__ stats)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
     double sum[7] = {0, 0, 0, 0, 0, 0, 0}, sq[7] = {0, 0, 0, 0, 0, 0, 0};
     double ph[NH], ps[NS];
     for (int i = 0; i < NH; ++i) ph[i] = 0;
     for (int i = 0; i < NS; ++i) ps[i] = 0;
-    for (int t = 0; t < s; ++t) {
+    for (int t = lane; t < s; t += 64) {
         const float *o = box + ((size_t)t * b + f) * BOX;
         const float *c = c1 + ((size_t)t * b + f) * 3;
         double v[7];
@@ -51,6 +60,10 @@ __global__ void mc_statistics_kernel(int s, int b, const float *__restrict__ box
         for (int i = 0; i < NH; ++i) ph[i] += eh[i] / zh;
         for (int i = 0; i < NS; ++i) ps[i] += es[i] / zs;
     }
+    for (int d = 0; d < 7; ++d) { sum[d] = wave_sum(sum[d]); sq[d] = wave_sum(sq[d]); }
+    for (int i = 0; i < NH; ++i) ph[i] = wave_sum(ph[i]);
+    for (int i = 0; i < NS; ++i) ps[i] = wave_sum(ps[i]);
+    if (lane != 0) return;
     float *out = stats + (size_t)f * 30;
     double tv = 0;
     for (int d = 0; d < 7; ++d) {
@@ -85,7 +98,7 @@ extern "C" int fpn_mc_statistics(int s, int b, const float *box_output, const fl
     FPN_REQUIRE(s >= 1 && b >= 0, "mc_statistics: need at least one sample");
     if (b == 0) return FPN_OK;
     FPN_REQUIRE(box_output && stage1_center && stats, "mc_statistics: null pointer");
-    hipLaunchKernelGGL(mc_statistics_kernel, dim3((b + 63) / 64), dim3(64), 0, as_stream(stream), s, b, box_output,
+    hipLaunchKernelGGL(mc_statistics_kernel, dim3((unsigned)b), dim3(64), 0, as_stream(stream), s, b, box_output,
                        stage1_center, stats);
     return check_launch("fpn_mc_statistics");
 }
