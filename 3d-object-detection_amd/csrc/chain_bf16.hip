@@ -392,6 +392,48 @@ __device__ __forceinline__ void stage_consts(float *dst, const float *__restrict
     }
 }
 
+// The same in two steps, for a kernel's opening: request() only asks for the vectors, put() writes them to LDS.
+// A write placed right behind its own load makes the wave wait there - for every load asked for before it, the
+// weight ring's first units included - and only then ask for its inputs: two trips to memory one after the
+// other.  With every load of the opening requested first, the waits that follow are for one trip.
+template <int N>
+struct StagedConsts {
+    static_assert(N % 4 == 0 && N <= 1024, "whole 16-byte vectors, four a lane at most");
+    static constexpr int kVecs = (N / 4 + 63) / 64;
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    vec4 v0, v1, v2, v3;        // (register vectors by name: an array of float4 the compiler kept in scratch memory)
+    template <int I>
+    static __device__ __forceinline__ void get(vec4 &v, const float *__restrict__ src, unsigned lane)
+    {
+        const int k = I * 64 + (int)lane;
+        if constexpr (I < kVecs) {
+            if ((N / 4) % 64 == 0 || k < N / 4) v = reinterpret_cast<const vec4 *>(src)[k];
+        }
+    }
+    template <int I>
+    static __device__ __forceinline__ void set(float *dst, const vec4 &v, unsigned lane)
+    {
+        const int k = I * 64 + (int)lane;
+        if constexpr (I < kVecs) {
+            if ((N / 4) % 64 == 0 || k < N / 4) reinterpret_cast<vec4 *>(dst)[k] = v;
+        }
+    }
+    __device__ __forceinline__ void request(const float *__restrict__ src, unsigned lane)
+    {
+        get<0>(v0, src, lane);
+        get<1>(v1, src, lane);
+        get<2>(v2, src, lane);
+        get<3>(v3, src, lane);
+    }
+    __device__ __forceinline__ void put(float *dst, unsigned lane) const
+    {
+        set<0>(dst, v0, lane);
+        set<1>(dst, v1, lane);
+        set<2>(dst, v2, lane);
+        set<3>(dst, v3, lane);
+    }
+};
+
 // relu(acc + shift) as the next layer's operand, three instructions per register pair:
 // packed add, packed conversion, and the clamp as a packed 16-bit INTEGER max with 0 on
 // the bf16 bit patterns (negative floats, -0 included, are the negative integers).
@@ -918,10 +960,13 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     feed.start(p.ws, lane, feed_ring<Feed>());
     __shared__ float hconst[kWaves][64 + 64 + 128 + 1024];
     float *lc = hconst[threadIdx.x >> 6];
-    stage_consts<64>(lc, p.sh2, lane);
-    stage_consts<64>(lc + 64, p.sh3, lane);
-    stage_consts<128>(lc + 128, p.sh4, lane);
-    stage_consts<1024>(lc + 256, p.sh5, lane);
+    StagedConsts<64> c2, c3;
+    StagedConsts<128> c4;
+    StagedConsts<1024> c5;
+    c2.request(p.sh2, lane);
+    c3.request(p.sh3, lane);
+    c4.request(p.sh4, lane);
+    c5.request(p.sh5, lane);
     const float *sh2 = lc, *sh3 = lc + 64, *sh4 = lc + 128, *sh5 = lc + 256;
     Act a1[NP][2], a2[NP][2], a3[NP][2], a4[NP][4];
     {
@@ -934,6 +979,11 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[g][k] = k < p.cpc ? src[k] : 0.f;
         }
+        __builtin_amdgcn_sched_barrier(0);      // (the constants' writes stay behind the requests above)
+        c2.put(lc, lane);
+        c3.put(lc + 64, lane);
+        c4.put(lc + 128, lane);
+        c5.put(lc + 256, lane);
         FPN_HSTAMP(1);
         first.apply(a1, x, h);
     }
@@ -1279,35 +1329,44 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, feed_ring<Feed>(), ws);
     bf16x8 *park = park7 + (kPark ? (threadIdx.x >> 6) * (kParkVecs * 64) + lane : 0);
 
+    // the opening's loads, all requested before the first LDS write (a write right behind its load would make
+    // the wave wait there for everything asked so far, and ask for the rest only then): the conv6 shifts of
+    // the frustum, the later layers' constants, the points' dropout bits - wanted at the very end: requested
+    // there, they would be waited for with nothing left to compute - and conv6's operands
     float *sh6 = shift6[threadIdx.x >> 6];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(p.gshift + (row0 / p.n) * 512);   // (a wave's points lie in one frustum)
-        const float4 lo = src[lane], hi = src[64 + lane];
-        const float4 c7 = reinterpret_cast<const float4 *>(p.sh7)[lane];
-        const float4 c89 = reinterpret_cast<const float4 *>(lane < 32 ? p.sh8 : p.sh9)[lane & 31];
-        const float4 c10 = reinterpret_cast<const float4 *>(p.w10)[lane];
-        reinterpret_cast<float4 *>(sh6)[lane] = lo;
-        reinterpret_cast<float4 *>(sh6)[64 + lane] = hi;
-        reinterpret_cast<float4 *>(sh6 + kSh7)[lane] = c7;
-        reinterpret_cast<float4 *>(sh6 + kSh8)[lane] = c89;         // (conv8's 128 shifts, then conv9's)
-        reinterpret_cast<float4 *>(sh6 + kW10)[lane] = c10;
-    }
-    const float *sh7 = sh6 + kSh7, *sh8 = sh6 + kSh8, *sh9 = sh6 + kSh9, *w10 = sh6 + kW10;
-    // ... and the points' dropout bits, wanted at the very end: requested there, they would be waited for
-    // with nothing left to compute
     __shared__ uint4 keep_bits[kWaves][NP][64];
     uint4 *keep_w = keep_bits[threadIdx.x >> 6][0];
-    if (p.drop) {
-#pragma unroll
-        for (int g = 0; g < NP; ++g) keep_w[g * 64 + lane] = *reinterpret_cast<const uint4 *>(p.drop + (row0 + 32 * g + pt) * 4);
-    }
     Act pf[NP][2];
+    {
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
+        const vec4 *src = reinterpret_cast<const vec4 *>(p.gshift + (row0 / p.n) * 512);   // (a wave's points lie in one frustum)
+        const vec4 lo = src[lane], hi = src[64 + lane];
+        const vec4 c7 = reinterpret_cast<const vec4 *>(p.sh7)[lane];
+        const vec4 c89 = reinterpret_cast<const vec4 *>(lane < 32 ? p.sh8 : p.sh9)[lane & 31];
+        const vec4 c10 = reinterpret_cast<const vec4 *>(p.w10)[lane];
+        // (without dropout the same loads read the start of conv7's shifts instead, and nothing reads what they
+        // put in LDS: a branch round them made the compiler wait for every load before it on the other path)
+        uvec4 keep[NP];
 #pragma unroll
-    for (int g = 0; g < NP; ++g)
+        for (int g = 0; g < NP; ++g)
+            keep[g] = *reinterpret_cast<const uvec4 *>(p.drop ? p.drop + (row0 + 32 * g + pt) * 4 : reinterpret_cast<const unsigned *>(p.sh7));
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int g = 0; g < NP; ++g)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) pf[g][t].m[s] = p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h];
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) pf[g][t].m[s] = p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h];
+        __builtin_amdgcn_sched_barrier(0);
+        reinterpret_cast<vec4 *>(sh6)[lane] = lo;
+        reinterpret_cast<vec4 *>(sh6)[64 + lane] = hi;
+        reinterpret_cast<vec4 *>(sh6 + kSh7)[lane] = c7;
+        reinterpret_cast<vec4 *>(sh6 + kSh8)[lane] = c89;           // (conv8's 128 shifts, then conv9's)
+        reinterpret_cast<vec4 *>(sh6 + kW10)[lane] = c10;
+#pragma unroll
+        for (int g = 0; g < NP; ++g) reinterpret_cast<uvec4 *>(keep_w)[g * 64 + lane] = keep[g];
+    }
+    const float *sh7 = sh6 + kSh7, *sh8 = sh6 + kSh8, *sh9 = sh6 + kSh9, *w10 = sh6 + kW10;
 
     Act a7[NP][8];
     {
@@ -1453,9 +1512,12 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     feed.start(p.ws, lane, feed_ring<Feed>());
     __shared__ float oconst[kWaves][128 + 256 + (BOX ? 512 : 0)];
     float *lc = oconst[threadIdx.x >> 6];
-    stage_consts<128>(lc, p.sh2, lane);
-    stage_consts<256>(lc + 128, p.sh3, lane);
-    if constexpr (BOX) stage_consts<512>(lc + 384, p.sh4, lane);
+    StagedConsts<128> c2;
+    StagedConsts<256> c3;
+    StagedConsts<BOX ? 512 : 4> c4;
+    c2.request(p.sh2, lane);
+    c3.request(p.sh3, lane);
+    if constexpr (BOX) c4.request(p.sh4, lane);
     const float *sh2 = lc, *sh3 = lc + 128, *sh4 = lc + 384;
     Act a1[NP][4], a2[NP][4];
     {
@@ -1469,6 +1531,10 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
             for (int k = 0; k < 3; ++k) x[g][k] = src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f);
             x[g][3] = 0.f;
         }
+        __builtin_amdgcn_sched_barrier(0);      // (the constants' writes stay behind the requests above)
+        c2.put(lc, lane);
+        c3.put(lc + 128, lane);
+        if constexpr (BOX) c4.put(lc + 384, lane);
         first.apply(a1, x, h);
     }
     constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
