@@ -27,13 +27,19 @@ def disassemble(path):
 
 
 def demangle(n):
-    try:
-        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip()
-    except OSError:
-        return n
+    for tool in (LLVM + "llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool, n], capture_output=True, text=True).stdout.strip()
+        except OSError:
+            continue
+        if out:
+            return out
+    return n
 
 
 def main():
+    if len(sys.argv) < 2 or sys.argv[1] in ("-h", "--help") or not os.path.isfile(sys.argv[1]):
+        sys.exit(__doc__)
     txt = open(sys.argv[1]).read() if sys.argv[1].endswith(".s") else disassemble(sys.argv[1])
     want = sys.argv[2:]
     parts = re.split(r"\n(?=_Z[A-Za-z0-9_]*:)", txt)
