@@ -630,10 +630,15 @@ __device__ __forceinline__ void layer_t(Out (&out)[NP][NT], const Act (&in)[NP][
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// The transposed layer with the shifts as the accumulators' starting values (made for
-// LdsFeed: the shifts lie in LDS, a pair's are read during the last unit of the pair before;
-// with RingFeed the same arithmetic, the shifts then come from memory).  csh: the
-// shifts of the layer's FIRST pair, read by the caller early enough.
+// The transposed layer with the shifts as the accumulators' starting values: the epilogue
+// of a tile is conversion and clamp alone, 16 vector instructions instead of 24 (one wave per
+// SIMD issues in order: with five vector instructions per MFMA the stream itself, not the
+// matrix pipe, set the pace of the v1 kernels).  For shifts that lie in LDS - a pair's are
+// read during the last unit of the pair before; with shifts in memory the same arithmetic,
+// but the read then waits behind the weight ring's loads.  csh: the shifts of the layer's
+// FIRST pair, read by the caller early enough.  relu(acc + shift) with the sum started at
+// 0 and the sum started at the shift round differently: kernels that are compared bit for
+// bit use the same form.
 struct NoHook {
     template <class I>
     __device__ __forceinline__ void operator()(I) const {}
@@ -646,7 +651,7 @@ __device__ __forceinline__ void layer_t_from(Out (&out)[NP][NT], const Act (&in)
                                              const float *__restrict__ sh, Feed &feed, int h, TileConst (&csh)[2],
                                              Hook &&hook = Hook())
 {
-    static_assert(NJ >= 2 && Feed::kMode != 1, "unsupported layer shape");
+    static_assert(NJ >= 2, "unsupported layer shape");
     constexpr int NPAIR = (NT + 1) / 2;
     constexpr int U = NPAIR * NJ;
     floatx16 acc[2][2][NP];
@@ -670,6 +675,7 @@ __device__ __forceinline__ void layer_t_from(Out (&out)[NP][NT], const Act (&in)
         hook(I);
         sched_unit<Feed::kMode, 2 * ntile * NP, more ? 4 + 4 * nnext : 4,
                    (tp > 0 && j < 2) ? (32 * NP + 2 * ntile * NP - 1) / (2 * ntile * NP) : 1, NHOOK>();
+        feed.template sync<slot>();
     });
     constexpr int last = (NPAIR - 1) & 1;
 #pragma unroll
@@ -678,6 +684,18 @@ __device__ __forceinline__ void layer_t_from(Out (&out)[NP][NT], const Act (&in)
         if constexpr (NT % 2 == 0) finish0(out[g][NT - 1], acc[last][1][g]);
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// layer_t_from with the first pair's shifts read here (constants that lie in the wave's LDS: the read is
+// short and stands in no queue behind the weight loads)
+template <int NP, int NJ, int NT, int R0, class Out, class Feed>
+__device__ __forceinline__ void layer_t_acc(Out (&out)[NP][NT], const Act (&in)[NP][NJ], const bf16x8 *__restrict__ ws,
+                                            const float *__restrict__ sh, Feed &feed, int h)
+{
+    TileConst csh[2];
+    load_const(csh[0], sh, 4 * h);
+    if constexpr (NT > 1) load_const(csh[1], sh, 32 + 4 * h);
+    layer_t_from<NP, NJ, NT, R0>(out, in, ws, sh, feed, h, csh);
 }
 
 // max over the wave's points of relu(acc + shift) for the lane's channel, merged into
@@ -990,10 +1008,10 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
     FPN_HSTAMP(2);
     constexpr int U2 = units_of(64, 64), U3 = units_of(64, 64), U4 = units_of(64, 128);
     const bf16x8 *ws = p.ws;
-    layer_t<NP, 2, 2, 0>(a2, a1, ws, sh2, feed, h);
+    layer_t_acc<NP, 2, 2, 0>(a2, a1, ws, sh2, feed, h);
     FPN_HSTAMP(3);
     ws += U2 * kUnitVecs;
-    layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws, sh3, feed, h);
+    layer_t_acc<NP, 2, 2, U2 % kRing>(a3, a2, ws, sh3, feed, h);
     FPN_HSTAMP(4);
     ws += U3 * kUnitVecs;
 #pragma unroll
@@ -1002,7 +1020,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h] = a3[g][t].m[s];
-    layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, sh4, feed, h);
+    layer_t_acc<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws, sh4, feed, h);
     FPN_HSTAMP(5);
     ws += U4 * kUnitVecs;
     if (pool.on) {      // (two copies of the layer: LDS and memory atomics are different instructions)
@@ -1101,9 +1119,9 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_frustum_bf16_kernel(cons
             first.apply(a1, x, h);
         }
         FPN_FSTAMP(3);
-        layer_t<NP, 2, 2, 0>(a2, a1, ws, sh2, feed, h);
+        layer_t_acc<NP, 2, 2, 0>(a2, a1, ws, sh2, feed, h);
         FPN_FSTAMP(4);
-        layer_t<NP, 2, 2, U2 % kRing>(a3, a2, ws + U2 * kUnitVecs, sh3, feed, h);
+        layer_t_acc<NP, 2, 2, U2 % kRing>(a3, a2, ws + U2 * kUnitVecs, sh3, feed, h);
         FPN_FSTAMP(5);
         const long row0 = f * p.n + r0;
         auto store_feat = [&]() {       // point_feat = conv3's output
@@ -1115,7 +1133,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_frustum_bf16_kernel(cons
                     for (int s2 = 0; s2 < 2; ++s2)
                         p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s2) * 2 + h] = a3[g][t].m[s2];
         };
-        layer_t<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws + (U2 + U3) * kUnitVecs, sh4, feed, h);
+        layer_t_acc<NP, 2, 4, (U2 + U3) % kRing>(a4, a3, ws + (U2 + U3) * kUnitVecs, sh4, feed, h);
         FPN_FSTAMP(6);
         layer_max<NP, 4, 32, (U2 + U3 + U4) % kRing>(a4, ws + (U2 + U3 + U4) * kUnitVecs, sh5, lmax, feed, lane);
         FPN_FSTAMP(7);
@@ -1192,16 +1210,16 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
     Act a6[1][16], a7[1][8], a8[1][4];
     floatx16 a9[1][4];
     FPN_TSTAMP(1);
-    layer_t<1, 2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, feed, h);
+    layer_t_acc<1, 2, 16, 0>(a6, pf, ws, p.gshift + (row0 / p.n) * 512, feed, h);
     FPN_TSTAMP(2);
     ws += U6 * kUnitVecs;
-    layer_t<1, 16, 8, U6 % kRing>(a7, a6, ws, p.sh7, feed, h);
+    layer_t_acc<1, 16, 8, U6 % kRing>(a7, a6, ws, p.sh7, feed, h);
     FPN_TSTAMP(3);
     ws += U7 * kUnitVecs;
-    layer_t<1, 8, 4, (U6 + U7) % kRing>(a8, a7, ws, p.sh8, feed, h);
+    layer_t_acc<1, 8, 4, (U6 + U7) % kRing>(a8, a7, ws, p.sh8, feed, h);
     FPN_TSTAMP(4);
     ws += U8 * kUnitVecs;
-    layer_t<1, 4, 4, (U6 + U7 + U8) % kRing>(a9, a8, ws, p.sh9, feed, h);
+    layer_t_acc<1, 4, 4, (U6 + U7 + U8) % kRing>(a9, a8, ws, p.sh9, feed, h);
     FPN_TSTAMP(5);
 
     // Monte-Carlo dropout before the head (models/FPointNet_Bayes.py:92): bit c of word j
@@ -1253,13 +1271,15 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_bf16_kernel(const TailPa
 //   Bj = a unit of conv7 that multiplies tile j of chunk c (one unit per pair of conv7's
 //        output tiles); while the B1 units issue, tile 0 of chunk c+1 is finished into the
 //        register tile the B0 units have just released, and tile 1 during the next B0 units.
-// No epilogue of conv6 is exposed, its shifts are requested six units before they are
-// wanted, and the registers it frees make room for NP = 2 point groups per wave: every
-// weight fragment is used twice, which halves what the feed has to deliver per MFMA.
-// Every accumulator sees the same MFMAs in the same order as in seg_tail_bf16_kernel (conv7
-// still adds its input tiles in ascending order), and the epilogues are the same
-// instructions: the logits are the same bits.  The stream is the same too; the kernel reads
-// its units in the order above (TailOrder::pos).
+// No epilogue of conv6 is exposed, and the registers it frees make room for NP = 2 point
+// groups per wave: every weight fragment is used twice, which halves what the feed has to
+// deliver per MFMA.  The shifts of conv6 and conv7 are the accumulators' starting values
+// (read from the wave's LDS one unit before the tile's first MFMA), so an epilogue is
+// conversion and clamp alone: a third fewer vector instructions next to the MFMAs, 4.5 % of
+// the kernel's time.  Every accumulator starts from the same value and sees the same MFMAs
+// in the same order as in seg_tail_bf16_kernel (conv7 still adds its input tiles in ascending
+// order): the logits are the same bits.  The stream is the same too; the kernel reads its
+// units in the order above (TailOrder::pos).
 // ---------------------------------------------------------------------------
 // P: pairs of conv7's output tiles per pass (4: all eight tiles at once; 2: two passes over conv6 - its 64
 // MFMAs per point group are then done twice, 15 % more matrix work, and conv7's live accumulators halve)
@@ -1304,8 +1324,8 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     const int pt = lane & 31, h = lane >> 5;
     const long row0 = ((long)logical_block(pin.copy_vecs) * kWaves + (threadIdx.x >> 6)) * (32 * NP);
     // conv6's shifts - the frustum's row of 512 floats - wait in the wave's OWN piece of LDS (each wave reads only
-    // what it wrote: no barrier) and come back one tile at a time, a unit or two before the epilogue that adds
-    // them: 16 registers instead of 64 for two tiles held six units ahead of their use
+    // what it wrote: no barrier) and come back a chunk's two tiles at a time, one unit before the MFMAs that
+    // start from them
     // The other constants of the wave's layers wait there too (conv7's, conv8's and conv9's shifts, conv10's
     // matrix, behind the 512 floats of conv6: see stage_consts; read from memory they cost 6 % of the kernel).
     constexpr int kSh7 = 512, kSh8 = kSh7 + 256, kSh9 = kSh8 + 128, kW10 = kSh9 + 128, kTailConsts = kW10 + 256;
@@ -1373,43 +1393,49 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
         floatx16 acc7[P][2][NP];
         floatx16 acc6[2][NP];
         Act a6c[NP][2];
-        TileConst c6;
+        // the shifts enter as the accumulators' starting values (unit_mfma_from): both tiles' shifts of conv6's
+        // chunk, or of a conv7 pair, are read from LDS during the unit before the one that starts from them
+        TileConst cin[2];
+        auto load_pair = [&](const float *sh, int tile0) {
+            load_const(cin[0], sh, 32 * tile0 + 4 * h);
+            load_const(cin[1], sh, 32 * (tile0 + 1) + 4 * h);
+        };
         static_for<0, Order::kFused>([&](auto I) {
             constexpr int S = decltype(I)::value, slot = S % Feed::kDepth;
             constexpr typename Order::What w = Order::what(S);
-            if constexpr (w.kind == 0) unit_mfma<w.idx == 0, true, w.idx>(acc6, feed.template cur<slot>(), pf);
-            else unit_mfma<(w.c == 0 && w.kind == 1), true, w.kind - 1>(acc7[w.idx], feed.template cur<slot>(), a6c);
+            constexpr bool first7 = w.c == 0 && w.kind == 1;        // the unit a conv7 pair starts with
+            if constexpr (w.kind == 0 && w.idx == 0 && w.c < 0) load_pair(sh6, 0);      // (a pass's opening: nothing to hide it behind)
+            if constexpr (w.kind == 0 && w.idx == 0) unit_mfma_from<2>(acc6, feed.template cur<slot>(), pf, cin);
+            else if constexpr (w.kind == 0) unit_mfma<false, true, w.idx>(acc6, feed.template cur<slot>(), pf);
+            else if constexpr (first7) unit_mfma_from<2>(acc7[w.idx], feed.template cur<slot>(), a6c, cin);
+            else unit_mfma<false, true, w.kind - 1>(acc7[w.idx], feed.template cur<slot>(), a6c);
             feed.template advance_at<slot>(ws + (size_t)Order::pos(S + Feed::kLook) * kUnitVecs);
             // riders.  During the B0 units of step c tile 1 of chunk c is finished (one point group per unit), during
             // its B1 units tile 0 of chunk c + 1; in a pass's prologue tile 0 of chunk 0 right behind the second A
-            // unit - the one epilogue of conv6 that nothing hides.  The shifts of the tile finished next are read
-            // from LDS as soon as the register tile is free.
+            // unit - the one epilogue of conv6 that nothing hides.
             constexpr bool ride1 = w.kind == 1 && w.idx < NP;                   // tile 1 of chunk c, group idx
             constexpr bool ride0 = w.kind == 2 && w.idx < NP && w.c < 7;        // tile 0 of chunk c + 1, group idx
-            if constexpr (ride1) finish(a6c[w.idx][1], acc6[1][w.idx], c6);
-            if constexpr (ride0) finish(a6c[w.idx][0], acc6[0][w.idx], c6);
-            if constexpr (w.kind == 0 && w.idx == 0 && w.c < 0) load_const(c6, sh6, 4 * h);                      // chunk 0, tile 0
-            if constexpr (w.kind == 0 && w.idx == 0 && w.c >= 0) load_const(c6, sh6, 64 * (w.c + 1) + 4 * h);    // chunk c + 1, tile 0
-            if constexpr (w.kind == 2 && w.idx == P - 1 && w.c < 7) load_const(c6, sh6, 64 * (w.c + 1) + 32 + 4 * h);   // chunk c + 1, tile 1
-            sched_unit<Feed::kMode, 4 * NP, 4, (ride0 || ride1) ? (28 + 4 * NP - 1) / (4 * NP) : 1>();
+            if constexpr (ride1) finish0(a6c[w.idx][1], acc6[1][w.idx]);
+            if constexpr (ride0) finish0(a6c[w.idx][0], acc6[0][w.idx]);
+            // the starting values of the next unit
+            if constexpr (w.kind == 0 && w.idx == 1 && w.c < 0) load_pair(sh7, 2 * (w.pass * P));                         // conv7, the pass's pair 0
+            if constexpr (first7 && w.idx < P - 1) load_pair(sh7, 2 * (w.pass * P + w.idx + 1));                          // ... its next pair
+            if constexpr (w.kind == 1 && w.idx == P - 1 && w.c < 7) load_pair(sh6, 2 * (w.c + 1));                        // conv6, chunk c + 1
+            sched_unit<Feed::kMode, 4 * NP, 4, (ride0 || ride1) ? (20 + 4 * NP - 1) / (4 * NP) : 1>();
             if constexpr (w.kind == 0 && w.idx == 1 && w.c < 0) {
 #pragma unroll
-                for (int g = 0; g < NP; ++g) finish(a6c[g][0], acc6[0][g], c6);
-                load_const(c6, sh6, 32 + 4 * h);    // chunk 0, tile 1
+                for (int g = 0; g < NP; ++g) finish0(a6c[g][0], acc6[0][g]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             feed.template sync<slot>();
             // a pass's end: conv7's epilogue for its tiles
             if constexpr (S % Order::kPass == Order::kPass - 1) {
-                TileConst c7;
 #pragma unroll
                 for (int tp = 0; tp < P; ++tp)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        load_const(c7, sh7, 32 * (2 * (w.pass * P + tp) + u) + 4 * h);
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int g = 0; g < NP; ++g) finish(a7[g][2 * (w.pass * P + tp) + u], acc7[tp][u][g], c7);
-                    }
+                        for (int g = 0; g < NP; ++g) finish0(a7[g][2 * (w.pass * P + tp) + u], acc7[tp][u][g]);
                 if constexpr (kPark && w.pass == 0) {
 #pragma unroll
                     for (int g = 0; g < NP; ++g)
@@ -1435,9 +1461,9 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     ws += (size_t)Order::kStream * kUnitVecs;
     Act a8[NP][4];
     floatx16 a9[NP][4];
-    layer_t<NP, 8, 4, Order::kFused % Feed::kDepth>(a8, a7, ws, sh8, feed, h);
+    layer_t_acc<NP, 8, 4, Order::kFused % Feed::kDepth>(a8, a7, ws, sh8, feed, h);
     ws += U8 * kUnitVecs;
-    layer_t<NP, 4, 4, (Order::kFused + U8) % Feed::kDepth>(a9, a8, ws, sh9, feed, h);
+    layer_t_acc<NP, 4, 4, (Order::kFused + U8) % Feed::kDepth>(a9, a8, ws, sh9, feed, h);
 
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
@@ -1539,14 +1565,14 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
     }
     constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256);
     const bf16x8 *ws = p.ws;
-    layer_t<NP, 4, 4, 0>(a2, a1, ws, sh2, feed, h);
+    layer_t_acc<NP, 4, 4, 0>(a2, a1, ws, sh2, feed, h);
     ws += U2 * kUnitVecs;
     if constexpr (!BOX) {
         if (pool.on) layer_max<NP, 4, 8, U2 % kRing>(a2, ws, sh3, lmax + pool.local * C, feed, lane);
         else layer_max<NP, 4, 8, U2 % kRing>(a2, ws, sh3, gmax, feed, lane);
     } else {
         Act a3[NP][8];
-        layer_t<NP, 4, 8, U2 % kRing>(a3, a2, ws, sh3, feed, h);
+        layer_t_acc<NP, 4, 8, U2 % kRing>(a3, a2, ws, sh3, feed, h);
         ws += U3 * kUnitVecs;
         if (pool.on) layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, sh4, lmax + pool.local * C, feed, lane);
         else layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws, sh4, gmax, feed, lane);
