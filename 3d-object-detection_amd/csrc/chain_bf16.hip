@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     // start from them
     // The other constants of the wave's layers wait there too (conv7's, conv8's and conv9's shifts, conv10's
     // matrix, behind the 512 floats of conv6: see stage_consts; read from memory they cost 6 % of the kernel).
-    constexpr int kSh7 = 512, kSh8 = kSh7 + 256, kSh9 = kSh8 + 128, kW10 = kSh9 + 128, kTailConsts = kW10 + 256;
+    constexpr int kSh7 = 512, kSh8 = kSh7 + 256, kSh9 = kSh8 + 128, kW10 = kSh9 + 128, kB10 = kW10 + 256, kTailConsts = kB10 + 4;
     __shared__ float shift6[kWaves][kTailConsts];
     // two passes: the first pass's half of conv7's output (64 registers of operand fragments for two point
     // groups) has nothing to do during the second pass and waits in the wave's own piece of LDS as well
@@ -1345,6 +1345,10 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
         p.w10 += f * (128 * 2);
     }
     const bf16x8 *ws = p.ws;
+#ifdef FPN_TAIL_STAMPS      // timing-only build: cycle stamps of one wave into the first logits (wrong results)
+    long long stamp[8];
+    stamp[0] = clock64();
+#endif
     Feed feed;
     feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, feed_ring<Feed>(), ws);
     bf16x8 *park = park7 + (kPark ? (threadIdx.x >> 6) * (kParkVecs * 64) + lane : 0);
@@ -1365,6 +1369,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
         const vec4 c7 = reinterpret_cast<const vec4 *>(p.sh7)[lane];
         const vec4 c89 = reinterpret_cast<const vec4 *>(lane < 32 ? p.sh8 : p.sh9)[lane & 31];
         const vec4 c10 = reinterpret_cast<const vec4 *>(p.w10)[lane];
+        const float cb10 = p.b10[lane & 1];
         // (without dropout the same loads read the start of conv7's shifts instead, and nothing reads what they
         // put in LDS: a branch round them made the compiler wait for every load before it on the other path)
         uvec4 keep[NP];
@@ -1383,11 +1388,13 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
         reinterpret_cast<vec4 *>(sh6 + kSh7)[lane] = c7;
         reinterpret_cast<vec4 *>(sh6 + kSh8)[lane] = c89;           // (conv8's 128 shifts, then conv9's)
         reinterpret_cast<vec4 *>(sh6 + kW10)[lane] = c10;
+        if (lane < 2) sh6[kB10 + lane] = cb10;
 #pragma unroll
         for (int g = 0; g < NP; ++g) reinterpret_cast<uvec4 *>(keep_w)[g * 64 + lane] = keep[g];
     }
     const float *sh7 = sh6 + kSh7, *sh8 = sh6 + kSh8, *sh9 = sh6 + kSh9, *w10 = sh6 + kW10;
 
+    FPN_TSTAMP(1);
     Act a7[NP][8];
     {
         floatx16 acc7[P][2][NP];
@@ -1445,6 +1452,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
                             for (int m = 0; m < 2; ++m) park[((g * 2 * P + t) * 2 + m) * 64] = a7[g][t].m[m];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                FPN_TSTAMP(2 + (w.pass == Order::kPasses - 1 ? 1 : 0));
             }
         });
         if constexpr (kPark) {
@@ -1461,9 +1469,12 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     ws += (size_t)Order::kStream * kUnitVecs;
     Act a8[NP][4];
     floatx16 a9[NP][4];
+    FPN_TSTAMP(4);
     layer_t_acc<NP, 8, 4, Order::kFused % Feed::kDepth>(a8, a7, ws, sh8, feed, h);
+    FPN_TSTAMP(5);
     ws += U8 * kUnitVecs;
     layer_t_acc<NP, 4, 4, (Order::kFused + U8) % Feed::kDepth>(a9, a8, ws, sh9, feed, h);
+    FPN_TSTAMP(6);
 
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
@@ -1478,24 +1489,41 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
                 for (int r = 0; r < 16; ++r) a9[g][j][r] *= (word >> (8 * (r >> 2) + (r & 3))) & 1u ? 2.f : 0.f;
             }
         }
-        // conv10 (128 -> 2) in fp32 on the vector ALU, as in seg_tail_bf16_kernel
-        float s0 = 0.f, s1 = 0.f;
+    }
+    // conv10 (128 -> 2) in fp32 on the vector ALU, as in seg_tail_bf16_kernel: per point group the same fused
+    // multiply-adds in the same order.  Both logits of a channel in one packed instruction (no MFMA runs beside
+    // these, where a packed instruction would cost more than its two halves), the point groups side by side - one
+    // LDS read of a weight pair serves both, and their sums are independent chains - and the bias from LDS: read
+    // from memory here, it was a whole trip to memory with nothing else to do.
+    floatx2 s01[NP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int g = 0; g < NP; ++g) s01[g] = floatx2{0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 *w = reinterpret_cast<const float4 *>(w10 + (32 * j + 8 * q + 4 * h) * 2);
-                const float4 wa = w[0], wb = w[1];
-                s0 = fmaf(a9[g][j][4 * q + 0], wa.x, s0); s1 = fmaf(a9[g][j][4 * q + 0], wa.y, s1);
-                s0 = fmaf(a9[g][j][4 * q + 1], wa.z, s0); s1 = fmaf(a9[g][j][4 * q + 1], wa.w, s1);
-                s0 = fmaf(a9[g][j][4 * q + 2], wb.x, s0); s1 = fmaf(a9[g][j][4 * q + 2], wb.y, s1);
-                s0 = fmaf(a9[g][j][4 * q + 3], wb.z, s0); s1 = fmaf(a9[g][j][4 * q + 3], wb.w, s1);
-            }
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const floatx2 *w = reinterpret_cast<const floatx2 *>(w10 + (32 * j + 8 * q + 4 * h) * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int g = 0; g < NP; ++g) {
+                    const float a = a9[g][j][4 * q + e];
+                    s01[g] = __builtin_elementwise_fma(floatx2{a, a}, w[e], s01[g]);
+                }
+        }
+    const floatx2 b10 = *reinterpret_cast<const floatx2 *>(sh6 + kB10);
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+        float s0 = s01[g][0], s1 = s01[g][1];
         s0 += __shfl_xor(s0, 32);
         s1 += __shfl_xor(s1, 32);
-        if (h == 0)
-            *reinterpret_cast<float2 *>(p.logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + p.b10[0], s1 + p.b10[1]);
+        if (h == 0) *reinterpret_cast<float2 *>(p.logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + b10[0], s1 + b10[1]);
     }
+#ifdef FPN_TAIL_STAMPS
+    stamp[7] = clock64();
+    if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<long long *>(p.logits)[32 + i] = stamp[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------

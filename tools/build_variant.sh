@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 unit=${FPN_VARIANT_UNIT:-chain_bf16}
 nonan=""
-if [ "$unit" = chain_bf16 ]; then nonan=-fno-honor-nans; fi
+if [ "$unit" = chain_bf16 ]; then nonan="-fno-honor-nans -fno-slp-vectorize"; fi
 cd "$(dirname "$0")/../3d-object-detection_amd/csrc"
 mkdir -p ../../tools/bin build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -fhip-fp32-correctly-rounded-divide-sqrt \

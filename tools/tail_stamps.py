@@ -17,13 +17,17 @@ def main():
     pc, oh = torch.from_numpy(pc_np).to(dev), torch.from_numpy(oh_np).to(dev)
     st = variables.VariableStore(dev, seed=1)
     pl = plan.V1Plan(st, 4, precision="bf16")
-    names = ["start", "inputs + first units", "conv6 (16 units)", "conv7 (64)", "conv8 (16)", "conv9 (8)", "conv10 + store"]
+    fused = os.environ.get("FPN_BF16_TAIL", "fused2") != "layers"
+    names = ["start", "opening (constants, inputs, first units)", "conv6 + conv7, pass 1", "pass 2", "(stamp)", "conv8 (16 units)",
+             "conv9 (8)", "dropout + conv10 + store"] if fused else \
+        ["start", "inputs + first units", "conv6 (16 units)", "conv7 (64)", "conv8 (16)", "conv9 (8)", "conv10 + store"]
     for _ in range(3):
         ep = pl.forward(pc, oh)
     torch.cuda.synchronize()
-    t = ep["mask_logits"].reshape(-1)[64:78].view(torch.int64).cpu().tolist()
-    print(os.environ.get("FPN_BF16_FEED", "lds"), ", ".join("%s +%d" % (names[k], t[k] - t[k - 1]) for k in range(1, 7)), "| total", t[6] - t[0])
-
+    n = len(names)
+    t = ep["mask_logits"].reshape(-1)[64:64 + 2 * n].view(torch.int64).cpu().tolist()
+    print(os.environ.get("FPN_BF16_TAIL", "fused2"), os.environ.get("FPN_BF16_FEED", "ring"),
+          ", ".join("%s +%d" % (names[k], t[k] - t[k - 1]) for k in range(1, n)), "| total", t[n - 1] - t[0])
 
 if __name__ == "__main__":
     main()
