@@ -883,7 +883,10 @@ struct FirstLayer {
             __bf16 hi[KP], lo[KP];
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const float w = k < k_total ? w1[k * (32 * NT) + 32 * t + c] * scale : 0.f;
+                // (the load itself is unconditional - row 0 stands in past the last channel: a load inside a
+                // branch makes the wave wait there for every load requested so far, a trip to memory per channel)
+                const float wk = w1[(k < k_total ? k : 0) * (32 * NT) + 32 * t + c];
+                const float w = k < k_total ? wk * scale : 0.f;
                 hi[k] = (__bf16)w;
                 lo[k] = (__bf16)(w - (float)hi[k]);
             }
@@ -995,7 +998,10 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_bf16_kernel(const HeadPa
         for (int g = 0; g < NP; ++g) {
             const float *src = p.pc + (row0 + 32 * g + pt) * p.cpc;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[g][k] = k < p.cpc ? src[k] : 0.f;
+            for (int k = 0; k < 8; ++k) {       // (unconditional loads, as in FirstLayer::load)
+                const float xk = src[k < p.cpc ? k : 0];
+                x[g][k] = k < p.cpc ? xk : 0.f;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);      // (the constants' writes stay behind the requests above)
         c2.put(lc, lane);
@@ -1059,15 +1065,18 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_frustum_bf16_kernel(cons
     static_assert((U2 + U3 + U4 + U5) % kRing == 0, "the ring's slots must come round with the stream");
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
-    const long f = logical_block(pin.copy_vecs);
+    __shared__ int lmax[1024];
+    __shared__ float hconst[64 + 64 + 128 + 1024];
+    __shared__ float xin[kHeadXin];
+    // a workgroup per frustum (grid = frustums), or fewer workgroups that each walk every gridDim-th frustum
+    const long frustums = pin.rows / pin.n;
+#pragma unroll 1
+    for (long f = gridDim.x == frustums ? (long)logical_block(pin.copy_vecs) : (long)blockIdx.x; f < frustums; f += gridDim.x) {
     HeadParams p = pin;
     if (pin.copy_vecs) {
         p.ws += (size_t)f * pin.copy_vecs;
         p.w1 += (size_t)f * (size_t)(pin.cpc * 64);
     }
-    __shared__ int lmax[1024];
-    __shared__ float hconst[64 + 64 + 128 + 1024];
-    __shared__ float xin[kHeadXin];
 
 #ifdef FPN_HEAD_STAMPS
     long long stamp[12];
@@ -1080,18 +1089,38 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_frustum_bf16_kernel(cons
     FirstLayer<2, 8> first;
     first.load(p.w1, p.cpc, p.sc1, p.sh1, lane, h);
     {
+        // every load of the set-up is requested before its first LDS write, and without a branch round any of
+        // them (indices past the end read vector 0 instead; only the writes are conditional): a write right
+        // behind its load, or a load inside a branch, makes the wave wait for all loads requested so far - a trip
+        // to memory per step instead of one
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        constexpr int kThreads = 64 * kWaves, kXv = kHeadXin / 4 / kThreads;
         const int vecs = p.n * p.cpc / 4;
-        const float4 *src = reinterpret_cast<const float4 *>(p.pc + (size_t)f * p.n * p.cpc);
-        for (int i = threadIdx.x; i < vecs; i += 64 * kWaves) reinterpret_cast<float4 *>(xin)[i] = src[i];
-        for (int i = threadIdx.x; i < 1024; i += 64 * kWaves) lmax[i] = 0;
-        if (wave == 0) {
-            stage_consts<64>(hconst, p.sh2, lane);
-            stage_consts<64>(hconst + 64, p.sh3, lane);
-        } else if (wave == 1) {
-            stage_consts<128>(hconst + 128, p.sh4, lane);
-        } else {
-            stage_consts<512>(hconst + 256 + 512 * (wave - 2), p.sh5 + 512 * (wave - 2), lane);
+        const vec4 *src = reinterpret_cast<const vec4 *>(p.pc + (size_t)f * p.n * p.cpc);
+        vec4 xv[kXv];
+#pragma unroll
+        for (int i = 0; i < kXv; ++i) {
+            const int k = i * kThreads + (int)threadIdx.x;
+            xv[i] = src[k < vecs ? k : 0];
         }
+        // the layers' constants, 320 vectors in hconst's order: conv2's 16, conv3's 16, conv4's 32, conv5's 256
+        constexpr int kConstVecs = (64 + 64 + 128 + 1024) / 4;
+        static_assert(kConstVecs <= 2 * kThreads, "two vectors a thread");
+        auto const_vec = [&](int k) {
+            const float *base = k < 16 ? p.sh2 : k < 32 ? p.sh3 - 64 : k < 64 ? p.sh4 - 128 : p.sh5 - 256;
+            return reinterpret_cast<const vec4 *>(base)[k];
+        };
+        const int k1 = (int)threadIdx.x + kThreads;
+        const vec4 cv0 = const_vec((int)threadIdx.x), cv1 = const_vec(k1 < kConstVecs ? k1 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kXv; ++i) {
+            const int k = i * kThreads + (int)threadIdx.x;
+            if (k < vecs) reinterpret_cast<vec4 *>(xin)[k] = xv[i];
+        }
+        for (int i = threadIdx.x; i < 1024; i += kThreads) lmax[i] = 0;
+        reinterpret_cast<vec4 *>(hconst)[threadIdx.x] = cv0;
+        if (k1 < kConstVecs) reinterpret_cast<vec4 *>(hconst)[k1] = cv1;
     }
     __syncthreads();
     const float *sh2 = hconst, *sh3 = hconst + 64, *sh4 = hconst + 128, *sh5 = hconst + 256;
@@ -1114,7 +1143,10 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_frustum_bf16_kernel(cons
             for (int g = 0; g < NP; ++g) {
                 const float *src = xin + (r0 + 32 * g + pt) * p.cpc;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) x[g][k] = k < p.cpc ? src[k] : 0.f;
+                for (int k = 0; k < 8; ++k) {       // (unconditional reads, as in FirstLayer::load)
+                    const float xk = src[k < p.cpc ? k : 0];
+                    x[g][k] = k < p.cpc ? xk : 0.f;
+                }
             }
             first.apply(a1, x, h);
         }
@@ -1151,6 +1183,9 @@ __global__ __launch_bounds__(64 * kWaves) void seg_head_frustum_bf16_kernel(cons
     if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
         for (int i = 0; i < 11; ++i) reinterpret_cast<long long *>(pin.gmax)[32 + i] = stamp[i];
 #endif
+    // (the next frustum's set-up writes xin and hconst, which every wave has finished reading at the barrier
+    // above, and lmax entries that this same thread has just read)
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2596,7 +2631,11 @@ int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void 
         // too: conv5 24.9 k cycles a round against 24.1 k)
         // (four point groups per wave - every fragment used four times - fill the register file: conv5's two
         // accumulator sets 256, its input 128, the ring 64; the compiler spilled inside the loop: 0.48 ms against 0.24)
-        hipLaunchKernelGGL((seg_head_frustum_bf16_kernel<2, WrapRingFeedT<kRing>>), dim3((unsigned)frustums), dim3(64 * kWaves), 0, as_stream(stream), p);
+        // with two frustums or more per CU, one workgroup per CU that walks every cus-th frustum (1.2 % over a
+        // workgroup per frustum: no workgroup hand-overs); FPN_BF16_HEAD_GRID = another number of workgroups
+        const char *ge = std::getenv("FPN_BF16_HEAD_GRID");
+        const long grid = ge && std::atol(ge) > 0 ? std::min(frustums, std::atol(ge)) : (cus > 0 && frustums >= 2 * cus) ? cus : frustums;
+        hipLaunchKernelGGL((seg_head_frustum_bf16_kernel<2, WrapRingFeedT<kRing>>), dim3((unsigned)grid), dim3(64 * kWaves), 0, as_stream(stream), p);
         return check_launch("fpn_v1_seg_head_bf16");
     }
     if (groups_per_wave(n) == 2)

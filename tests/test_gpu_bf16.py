@@ -304,7 +304,8 @@ def test_bf16_head_forms_agree_bit_for_bit(device, monkeypatch, B, N, C):
     """The seg head with a workgroup per frustum (points in LDS, rounds over a wrapping weight
     ring, maxima merged in LDS) against the kernel whose waves take one round each: the same
     arithmetic per point, so point_feat and the frustum maxima are the same bits; shared
-    stream and one stream per frustum copy."""
+    stream and one stream per frustum copy.  "walk": two workgroups that each take every
+    second frustum (what the library does by itself from two frustums per CU on)."""
     from fpn import bayes, ops, plan, synthetic, variables
     st = variables.VariableStore(device, seed=14)
     plan.init_variables(st, C, True)
@@ -313,17 +314,21 @@ def test_bf16_head_forms_agree_bit_for_bit(device, monkeypatch, B, N, C):
     pc, _ = synthetic.make_frustums(B, N, C, seed=B + N)
     x = dev(pc, device).reshape(B * N, C)
     got = {}
-    for form in ("round", "frustum"):
-        monkeypatch.setenv("FPN_BF16_HEAD", form)
+    for form in ("round", "frustum", "walk"):
+        monkeypatch.setenv("FPN_BF16_HEAD", "frustum" if form == "walk" else form)
+        if form == "walk":
+            monkeypatch.setenv("FPN_BF16_HEAD_GRID", "2")
         point_feat = torch.zeros((B * N, 64), dtype=torch.bfloat16, device=device)
         gcat = torch.zeros((B, 1024 + 3), device=device)
         ops.v1_seg_head_bf16(x, N, net._head_ws, net._head_consts, point_feat, gcat)
         got[form] = (point_feat, gcat)
     assert float(got["round"][1].abs().max()) > 0 and float(got["round"][0].float().abs().max()) > 0
-    assert torch.equal(got["round"][0], got["frustum"][0])
-    assert torch.equal(got["round"][1], got["frustum"][1])
+    for form in ("frustum", "walk"):
+        assert torch.equal(got["round"][0], got[form][0]), form
+        assert torch.equal(got["round"][1], got[form][1]), form
     if C != 3:
         return
+    # (FPN_BF16_HEAD_GRID stays set: the per-copy streams below are walked two workgroups wide as well)
     # Flipout: per-copy streams through the whole plan
     st = variables.VariableStore(device, seed=16)
     bp = bayes.BayesPlan(st, 3, precision="bf16")
