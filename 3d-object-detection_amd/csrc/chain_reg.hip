@@ -627,7 +627,10 @@ __device__ __forceinline__ void layer_first(floatx16 (&out)[NT], const float (&x
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int k = 2 * s + h;
-            const float wv = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
+            // (an unconditional load - row 0 stands in past the last channel - and a select: a load inside a branch
+            // makes the wave wait for every load requested before it, a trip to memory per MFMA step here)
+            const float wk = w1[(k < k_total ? k : 0) * (32 * NT) + 32 * t + c];
+            const float wv = k < k_total ? wk : 0.f;
             out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, x[s], out[t], 0, 0, 0);
         }
     }
@@ -659,7 +662,8 @@ struct FirstLayerF32 {
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
                 const int k = 2 * s + h;
-                wv[t][s] = k < k_total ? w1[k * (32 * NT) + 32 * t + c] : 0.f;
+                const float wk = w1[(k < k_total ? k : 0) * (32 * NT) + 32 * t + c];      // (unconditional, as in layer_first)
+                wv[t][s] = k < k_total ? wk : 0.f;
             }
             load_const(csc[t], sc, 32 * t + 4 * h);
             load_const(csh[t], sh, 32 * t + 4 * h);
@@ -744,7 +748,10 @@ __global__ __launch_bounds__(64 * kHeadWaves) void seg_head_reg_kernel(const Seg
     float x[4];
     const float *src = p.pc + (row0 + pt) * p.cpc;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) x[s] = 2 * s + h < p.cpc ? src[2 * s + h] : 0.f;
+    for (int s = 0; s < 4; ++s) {       // (unconditional loads, as in layer_first)
+        const float xk = src[2 * s + h < p.cpc ? 2 * s + h : 0];
+        x[s] = 2 * s + h < p.cpc ? xk : 0.f;
+    }
     floatx16 a1[2], a2[2], a3[2], a4[4];
     layer_first<2, 4>(a1, x, p.w1, p.cpc, p.sc1, p.sh1, lane, h);
     FPN_STAMP(1);
@@ -821,7 +828,10 @@ __global__ __launch_bounds__(64 * kRegWaves) void obj_chain_reg_kernel(const Obj
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int k = 2 * s + h;
-        x[s] = k < 3 ? src[k] - (p.delta ? p.delta[frustum * 3 + k] : 0.f) : 0.f;
+        // (unconditional loads, as in layer_first; without a delta the frustum's own point stands in)
+        const int kc = k < 3 ? k : 0;
+        const float xk = src[kc], dk = (p.delta ? p.delta + frustum * 3 : src)[kc];
+        x[s] = k < 3 ? xk - (p.delta ? dk : 0.f) : 0.f;
     }
     floatx16 a1[4], a2[4];
     layer_first<4, 2>(a1, x, p.w1, 3, p.sc1, p.sh1, lane, h);
@@ -1019,7 +1029,8 @@ __global__ __launch_bounds__(64 * kRegWaves, W3LDS ? 2 : 1) void sa_persist_kern
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = 2 * s + h;
-            wv[t][s] = k < 3 + p.cf ? p.w1[k * (32 * NT1) + 32 * t + (lane & 31)] : 0.f;
+            const float wk = p.w1[(k < 3 + p.cf ? k : 0) * (32 * NT1) + 32 * t + (lane & 31)];      // (unconditional, as in layer_first)
+            wv[t][s] = k < 3 + p.cf ? wk : 0.f;
         }
     // input channel k = 2 s + h of this lane: dx, dy, dz, then the point's direct features
     float xr[4], cr[4];
@@ -1382,7 +1393,10 @@ __global__ __launch_bounds__(64 * kRegWaves, 1) void fp_head_pre_kernel(const Fp
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wv[t][s] = 2 * s + h < p.cb ? p.w1b[(2 * s + h) * 128 + 32 * t + (lane & 31)] : 0.f;
+        for (int s = 0; s < 4; ++s) {       // (unconditional loads, as in layer_first)
+            const float wk = p.w1b[(2 * s + h < p.cb ? 2 * s + h : 0) * 128 + 32 * t + (lane & 31)];
+            wv[t][s] = 2 * s + h < p.cb ? wk : 0.f;
+        }
 
     float4 pr[4][4];
     float xr[4];
@@ -1393,7 +1407,10 @@ __global__ __launch_bounds__(64 * kRegWaves, 1) void fp_head_pre_kernel(const Fp
 #pragma unroll
             for (int i = 0; i < 4; ++i) pr[t][i] = *reinterpret_cast<const float4 *>(p.pre + row * 128 + 32 * t + 8 * i + 4 * h);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xr[s] = 2 * s + h < p.cb ? p.xb[row * p.cb + 2 * s + h] : 0.f;
+        for (int s = 0; s < 4; ++s) {
+            const float xk = p.xb[row * p.cb + (2 * s + h < p.cb ? 2 * s + h : 0)];
+            xr[s] = 2 * s + h < p.cb ? xk : 0.f;
+        }
     };
     load_in(r0);
     WChunk ring[4];

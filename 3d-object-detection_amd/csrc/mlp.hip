@@ -824,10 +824,10 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 st.wa[i] = p.w[(long)(k + i) * cout + ca];
-                st.wb[i] = two ? p.w[(long)(k + i) * cout + cb] : 0.f;
+                st.wb[i] = p.w[(long)(k + i) * cout + cb];       // (cb is a valid column either way; used only if two)
                 if (FLIP) {
                     st.da[i] = p.w_delta[(long)(k + i) * cout + ca];
-                    st.db[i] = two ? p.w_delta[(long)(k + i) * cout + cb] : 0.f;
+                    st.db[i] = p.w_delta[(long)(k + i) * cout + cb];
                 }
             }
         } else {       // the block that holds the last channel: zero activations beyond it, clamped weight rows
@@ -838,10 +838,10 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
                 st.x[i] = ok ? xrow[kk] : 0.f;
                 if (FLIP) st.s[i] = ok ? srow[kk] : 0.f;
                 st.wa[i] = p.w[(long)kk * cout + ca];
-                st.wb[i] = two ? p.w[(long)kk * cout + cb] : 0.f;
+                st.wb[i] = p.w[(long)kk * cout + cb];
                 if (FLIP) {
                     st.da[i] = p.w_delta[(long)kk * cout + ca];
-                    st.db[i] = two ? p.w_delta[(long)kk * cout + cb] : 0.f;
+                    st.db[i] = p.w_delta[(long)kk * cout + cb];
                 }
             }
         }
