@@ -1282,6 +1282,24 @@ __global__ void tile_weights_reg_kernel(int cin, int cout, int jmajor, const flo
 // kernel reads: out[f][e] = wm[k][c] + dw[k][c] * sin[f][k] * sout[f][c] with (k, c) the
 // matrix element that lives at position e of `layout` (0 row-major, 1 / 2 the chunked
 // layout of tile_weights_reg_kernel, output-tile / input-tile major).
+// Flipout's sign vectors from random bits: sign i = +1 where bit (i % 32) of word i / 32 is set, else -1; a
+// thread writes four signs.  (Drawn as floats by the framework they took three launches over every sign - random
+// integers, times two, minus one; the bits are a 32nd of that.)
+__global__ void flipout_signs_kernel(long n, const unsigned *__restrict__ bits, float *__restrict__ signs)
+{
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const unsigned w = bits[i >> 5] >> (i & 31);
+    const float4 v = make_float4(w & 1u ? 1.f : -1.f, w & 2u ? 1.f : -1.f, w & 4u ? 1.f : -1.f, w & 8u ? 1.f : -1.f);
+    if (i + 3 < n) {
+        *reinterpret_cast<float4 *>(signs + i) = v;
+    } else {
+        signs[i] = v.x;
+        if (i + 1 < n) signs[i + 1] = v.y;
+        if (i + 2 < n) signs[i + 2] = v.z;
+    }
+}
+
 // blockIdx.y = a group of kFlipCopies consecutive frustum copies: the mean and the
 // perturbation are read once per group (copies of one Monte-Carlo sample are neighbours)
 // and only the signs differ, so the kernel is write-bound instead of re-reading both
@@ -1523,6 +1541,19 @@ int fpn_tile_weights_reg_f32(int cin, int cout, int jmajor, const float *w, floa
     hipLaunchKernelGGL(tile_weights_reg_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        as_stream(stream), cin, cout, jmajor, w, w_tiled);
     return check_launch("fpn_tile_weights_reg_f32");
+}
+
+int fpn_flipout_signs(long n, const void *bits, float *signs, void *stream)
+{
+    FPN_REQUIRE(n >= 0 && n < (1L << 40), "flipout_signs: bad size");
+    if (n == 0) return FPN_OK;
+    FPN_REQUIRE(bits && signs, "flipout_signs: null pointer");
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(bits) & 3) == 0 && (reinterpret_cast<uintptr_t>(signs) & 15) == 0,
+                "flipout_signs: bits must be 4-byte aligned, signs 16-byte aligned");
+    const long threads = (n + 3) / 4;
+    hipLaunchKernelGGL(flipout_signs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), n,
+                       static_cast<const unsigned *>(bits), signs);
+    return check_launch("fpn_flipout_signs");
 }
 
 int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const float *w_delta,

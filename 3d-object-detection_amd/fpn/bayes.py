@@ -65,11 +65,11 @@ def unpack_keep_bits(bits):
 
 class Noise(dict):
     """noise[scope] = (eps (S,cin,cout), sign_in (S,B,cin), sign_out (S,B,cout)) [+ "dropout"].
-    When drawn by BayesPlan.sample_noise the per-scope tensors are VIEWS into three shared
-    buffers (one generator call each): eps_all (S, E), the layers' perturbation draws back to
-    back (scope k at column offsets[k]); sign_all (S, B, W), the layers' input and output
-    signs back to back.  The chain path then scales all draws of a sample block by
-    softplus(rho) in one launch instead of one per layer."""
+    When drawn by BayesPlan.sample_noise the per-scope tensors are VIEWS into shared buffers
+    (one generator call each): eps_all (S, E), the layers' perturbation draws back to back
+    (scope k at column offsets[k]); the sign matrices of all layers, each (S, B, width) in one
+    piece, made from one random bit per sign (ops.flipout_signs).  The chain path then scales
+    all draws of a sample block by softplus(rho) in one launch instead of one per layer."""
     eps_all = None
     offsets = None
 
@@ -119,25 +119,35 @@ class BayesPlan:
         flip = [(scope, cin, cout) for scope, cin, cout, _, _ in self.table if scope in self.flip_scopes]
         up4 = lambda v: (v + 3) // 4 * 4          # noqa: E731  (every slot starts on a 16-byte boundary)
         total_e = sum(up4(cin * cout) for _, cin, cout in flip)
-        total_w = sum(up4(cin) + up4(cout) for _, cin, cout in flip)
-        # one call per kind of draw: all layers' N(0,1) perturbations, all layers' +-1 signs
+        # one call per kind of draw: all layers' N(0,1) perturbations; one random bit per sign, spread to +-1 floats
+        # by the library (drawn as floats - random integers, times two, minus one - the signs were three launches
+        # over 41 M values for 32 samples x 128 frustums).  Each layer's sign matrices lie back to back,
+        # (S, batch, width) with the row length rounded up to whole 16-byte groups (what the weight builders read)
+        # except for the fully connected layers, whose kernel wants dense matrices: no copies on the way there.
         eps_all = torch.randn((nsamples, total_e), device=dev, generator=generator)
-        sign_all = torch.randint(0, 2, (nsamples, batch, total_w), device=dev, generator=generator,
-                                 dtype=torch.float32).mul_(2.0).sub_(1.0)
+        copies = nsamples * batch
+        row = lambda scope, width: width if scope.startswith("fc") else up4(width)      # noqa: E731
+        total_s = sum(up4(copies * row(k, cin)) + up4(copies * row(k, cout)) for k, cin, cout in flip)
+        bits = torch.randint(-(1 << 31), 1 << 31, ((total_s + 31) // 32,), dtype=torch.int32, device=dev,
+                             generator=generator)
+        sign_all = ops.flipout_signs(bits, total_s)
         noise.eps_all, noise.offsets = eps_all, {}
         e = w = 0
         for scope, cin, cout in flip:
             noise.offsets[scope] = e
-            noise[scope] = (eps_all[:, e:e + cin * cout].unflatten(1, (cin, cout)),
-                            sign_all[:, :, w:w + cin], sign_all[:, :, w + up4(cin):w + up4(cin) + cout])
+            ri, ro = row(scope, cin), row(scope, cout)
+            si = sign_all[w:w + copies * ri].view(nsamples, batch, ri)[:, :, :cin]
+            w += up4(copies * ri)
+            so = sign_all[w:w + copies * ro].view(nsamples, batch, ro)[:, :, :cout]
+            w += up4(copies * ro)
+            noise[scope] = (eps_all[:, e:e + cin * cout].unflatten(1, (cin, cout)), si, so)
             e += up4(cin * cout)
-            w += up4(cin) + up4(cout)
         if self.mc_dropout:
             if points is None:
                 raise ValueError("sample_noise needs the number of points per frustum for the dropout mask")
-            bits = torch.randint(0, 1 << 32, (nsamples, batch, points, 4), dtype=torch.int64, device=dev,
-                                 generator=generator)
-            noise["dropout"] = bits.to(torch.int32)       # keeps the low 32 bits
+            # (all 32 bits of every word are fair: the range is the whole of int32)
+            noise["dropout"] = torch.randint(-(1 << 31), 1 << 31, (nsamples, batch, points, 4), dtype=torch.int32,
+                                             device=dev, generator=generator)
         return noise
 
     def _sigma(self, scope):

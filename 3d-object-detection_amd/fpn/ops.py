@@ -199,6 +199,20 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else t.shape[1]
 
 
+def flipout_signs(bits, n, out=None):
+    """+-1 float signs from random bits through fpn_flipout_signs: out[i] = +1 where bit i % 32 of the int32 word
+    bits[i // 32] is set, else -1; bits a contiguous int32 tensor of at least (n + 31) // 32 words."""
+    if bits.dtype != torch.int32 or not bits.is_contiguous() or bits.numel() * 32 < n:
+        raise ValueError("bits must be a contiguous int32 tensor of at least %d words" % ((n + 31) // 32))
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=bits.device)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n or out.device != bits.device:
+        raise ValueError("out must be a contiguous float32 tensor of %d elements on the device of bits" % n)
+    with torch.cuda.device(bits.device):
+        _lib.check(_lib.load().fpn_flipout_signs(int(n), _lib.ptr(bits), _lib.ptr(out), _lib.stream_of(bits)))
+    return out
+
+
 def flipout_weights(w_mean, w_delta, sign_in, sign_out, layout, out=None):
     """Effective Flipout weights per frustum through fpn_flipout_weights_f32:
     W_mean + diag(sign_in[f]) . W_delta[f // per] . diag(sign_out[f]) for every row f of

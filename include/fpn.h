@@ -338,6 +338,15 @@ int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const
                             void *stream);
 
 /*
+ * Flipout's sign vectors from random bits: signs[i] = +1 where bit (i % 32) of the 32-bit word bits[i / 32] is
+ * set, else -1 (i < n; bits holds (n + 31) / 32 words, 4-byte aligned; signs 16-byte aligned).  The layers of
+ * models/FPointNet_Bayes.py:54-68 draw theirs inside tensorflow_probability (a Rademacher draw per input and
+ * per output channel of every example); here the caller's generator supplies one bit per sign and this call
+ * spreads them - any fair bits give the same distribution.
+ */
+int fpn_flipout_signs(long n, const void *bits, float *signs, void *stream);
+
+/*
  * Weight layout of the fpn_v1_* chain kernels, whose waves keep all activations
  * in registers and feed the matrix cores' weight operand straight from memory:
  * one 4 KiB chunk per (32-row input tile j, 32-column output tile t) with

@@ -145,6 +145,62 @@ def test_flipout_moments(device):
     np.testing.assert_allclose(var, want_var, rtol=0.15)
 
 
+@pytest.mark.parametrize("n", [1, 3, 31, 32, 33, 4096, 100003])
+def test_flipout_signs_are_the_given_bits(device, n):
+    """fpn_flipout_signs: sign i = +1 where bit i % 32 of word i // 32 is set, else -1 - every
+    length (whole 16-byte groups and ragged ends), bit for bit against the definition."""
+    from fpn import ops
+    rng = np.random.RandomState(n)
+    words = rng.randint(0, 1 << 32, (n + 31) // 32, dtype=np.uint64).astype(np.uint32)
+    got = ops.flipout_signs(dev(words.view(np.int32), device), n).cpu().numpy()
+    i = np.arange(n)
+    want = np.where((words[i // 32] >> (i % 32).astype(np.uint32)) & 1, 1.0, -1.0).astype(np.float32)
+    np.testing.assert_array_equal(got, want)
+    with pytest.raises(ValueError):
+        ops.flipout_signs(dev(words.view(np.int32), device), 32 * words.size + 1)
+
+
+def test_sample_noise_layout_and_fairness(device):
+    """BayesPlan.sample_noise: every layer's sign matrices are +-1 with the documented shapes, dense for
+    the fully connected layers (their kernel takes them as they are), rows on 16-byte boundaries for the
+    others; signs and dropout bits are fair (|mean| within 5 standard errors) and a seeded generator
+    reproduces the draw."""
+    from fpn import bayes, variables
+    st = variables.VariableStore(device, seed=3)
+    bp = bayes.BayesPlan(st, 4, mc_dropout=True)
+    S, B, N = 3, 5, 64
+    g = torch.Generator(device=device)
+    g.manual_seed(77)
+    noise = bp.sample_noise(S, B, g, N)
+    table = {scope: (cin, cout) for scope, cin, cout, _, _ in bp.table}
+    total = 0.0
+    count = 0
+    for scope in bp.flip_scopes:
+        eps, si, so = noise[scope]
+        cin, cout = table[scope]
+        assert tuple(eps.shape) == (S, cin, cout) and tuple(si.shape) == (S, B, cin) and tuple(so.shape) == (S, B, cout)
+        for t in (si, so):
+            assert bool((t.abs() == 1).all()), scope
+            assert t.stride(2) == 1 and t.stride(0) == B * t.stride(1)
+            if scope.startswith("fc"):
+                assert t.is_contiguous(), scope
+            else:
+                assert t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0, scope
+            total += float(t.sum())
+            count += t.numel()
+    assert abs(total / count) < 5 / np.sqrt(count)
+    keep = bayes.unpack_keep_bits(noise["dropout"])
+    assert tuple(noise["dropout"].shape) == (S, B, N, 4) and noise["dropout"].dtype == torch.int32
+    per_bit = keep.reshape(-1, 128).mean(0).cpu().numpy()          # every bit position of every word
+    assert np.abs(per_bit - 0.5).max() < 5 * 0.5 / np.sqrt(S * B * N)
+    g.manual_seed(77)
+    again = bp.sample_noise(S, B, g, N)
+    for scope in bp.flip_scopes:
+        for a, b in zip(noise[scope], again[scope]):
+            assert torch.equal(a, b), scope
+    assert torch.equal(noise["dropout"], again["dropout"])
+
+
 def test_mc_statistics(device):
     from fpn import uncertainty
     rng = np.random.RandomState(4)
