@@ -209,6 +209,28 @@ struct WrapRingFeedT : RingFeedT<DEPTH> {
     }
 };
 
+// The seg tail's ring when a wave walks a frustum round after round: the kernel consumes the first units of its
+// stream out of stream order (TailOrder::pos), so the read-ahead past the stream's last unit goes on at the units
+// the next round consumes first.  first4[i] = stream position of the unit consumed i-th.
+template <int DEPTH>
+struct TailWrapFeedT : RingFeedT<DEPTH> {
+    const bf16x8 *base, *end;
+    int first4[DEPTH];
+    template <int PH>
+    __device__ __forceinline__ void advance(const bf16x8 *__restrict__ unit)
+    {
+        const bf16x8 *next = unit + (size_t)DEPTH * kUnitVecs;
+        if (next >= end) {
+            const int i = (int)((next - end) / kUnitVecs);
+            int pos = first4[0];
+#pragma unroll
+            for (int k = 1; k < DEPTH; ++k) pos = i == k ? first4[k] : pos;
+            next = base + (size_t)pos * kUnitVecs;
+        }
+        this->template advance_at<PH>(next);
+    }
+};
+
 struct CoopFeed {
     static constexpr int kMode = 1, kDepth = 4;
     WUnit frag[4];          // (indexed by stream position mod 4; kFeedRead + 1 of them are live)
@@ -1350,86 +1372,25 @@ struct TailOrder {
     }
 };
 
-template <int NP, int P, class Feed>
-__global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const TailParams pin)
+// One round of the fused tail: the wave's 32 NP points (conv6's operand fragments in pf, rows row0 ..) through
+// conv6 .. conv10; the constants in the wave's LDS block sh6 (offsets TailLds), the dropout bits in keep_w.
+// On entry the ring holds the units consumed first, on exit the read-ahead of conv9's last units (the padding
+// behind the stream, or with a wrapping feed the next round's first units).  between(): called before conv9.
+struct TailLds {
+    static constexpr int kSh7 = 512, kSh8 = kSh7 + 256, kSh9 = kSh8 + 128, kW10 = kSh9 + 128, kB10 = kW10 + 256, kFloats = kB10 + 4;
+};
+
+template <int NP, int P, class Feed, class Between>
+__device__ __forceinline__ void tail_round(const Act (&pf)[NP][2], const float *sh6, const uint4 *keep_w, bool drop, bf16x8 *park,
+                                           const bf16x8 *ws, Feed &feed, float *logits, long row0, unsigned lane,
+                                           long long *stamp, Between &&between)
 {
     using Order = TailOrder<P>;
-    static_assert(NP <= P, "a tile's riders need one unit per point group");
-    const unsigned lane = threadIdx.x & 63;
-    const int pt = lane & 31, h = lane >> 5;
-    const long row0 = ((long)logical_block(pin.copy_vecs) * kWaves + (threadIdx.x >> 6)) * (32 * NP);
-    // conv6's shifts - the frustum's row of 512 floats - wait in the wave's OWN piece of LDS (each wave reads only
-    // what it wrote: no barrier) and come back a chunk's two tiles at a time, one unit before the MFMAs that
-    // start from them
-    // The other constants of the wave's layers wait there too (conv7's, conv8's and conv9's shifts, conv10's
-    // matrix, behind the 512 floats of conv6: see stage_consts; read from memory they cost 6 % of the kernel).
-    constexpr int kSh7 = 512, kSh8 = kSh7 + 256, kSh9 = kSh8 + 128, kW10 = kSh9 + 128, kB10 = kW10 + 256, kTailConsts = kB10 + 4;
-    __shared__ float shift6[kWaves][kTailConsts];
-    // two passes: the first pass's half of conv7's output (64 registers of operand fragments for two point
-    // groups) has nothing to do during the second pass and waits in the wave's own piece of LDS as well
-    // (vector v of a lane at [v][lane]: consecutive 16-byte slots, no bank conflicts) - held in registers it
-    // pushed the compiler into parking values in accumulator registers and copying whole accumulator tiles around
     constexpr bool kPark = Order::kPasses == 2;
-    constexpr int kParkVecs = NP * P * 2 * 2;        // point groups x tiles of a pass x fragments
-    __shared__ bf16x8 park7[kPark ? kWaves * kParkVecs * 64 : 1];
-    if (row0 >= pin.rows) return;       // (never with a cooperative feed: the host launches it on full workgroups only)
-    TailParams p = pin;
-    if (pin.copy_vecs) {
-        const size_t f = scalar_index(row0 / pin.n);
-        p.ws += f * pin.copy_vecs;
-        p.w10 += f * (128 * 2);
-    }
-    const bf16x8 *ws = p.ws;
-#ifdef FPN_TAIL_STAMPS      // timing-only build: cycle stamps of one wave into the first logits (wrong results)
-    long long stamp[8];
-    stamp[0] = clock64();
-#endif
-    Feed feed;
-    feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, feed_ring<Feed>(), ws);
-    bf16x8 *park = park7 + (kPark ? (threadIdx.x >> 6) * (kParkVecs * 64) + lane : 0);
-
-    // the opening's loads, all requested before the first LDS write (a write right behind its load would make
-    // the wave wait there for everything asked so far, and ask for the rest only then): the conv6 shifts of
-    // the frustum, the later layers' constants, the points' dropout bits - wanted at the very end: requested
-    // there, they would be waited for with nothing left to compute - and conv6's operands
-    float *sh6 = shift6[threadIdx.x >> 6];
-    __shared__ uint4 keep_bits[kWaves][NP][64];
-    uint4 *keep_w = keep_bits[threadIdx.x >> 6][0];
-    Act pf[NP][2];
-    {
-        typedef float vec4 __attribute__((ext_vector_type(4)));
-        typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
-        const vec4 *src = reinterpret_cast<const vec4 *>(p.gshift + (row0 / p.n) * 512);   // (a wave's points lie in one frustum)
-        const vec4 lo = src[lane], hi = src[64 + lane];
-        const vec4 c7 = reinterpret_cast<const vec4 *>(p.sh7)[lane];
-        const vec4 c89 = reinterpret_cast<const vec4 *>(lane < 32 ? p.sh8 : p.sh9)[lane & 31];
-        const vec4 c10 = reinterpret_cast<const vec4 *>(p.w10)[lane];
-        const float cb10 = p.b10[lane & 1];
-        // (without dropout the same loads read the start of conv7's shifts instead, and nothing reads what they
-        // put in LDS: a branch round them made the compiler wait for every load before it on the other path)
-        uvec4 keep[NP];
-#pragma unroll
-        for (int g = 0; g < NP; ++g)
-            keep[g] = *reinterpret_cast<const uvec4 *>(p.drop ? p.drop + (row0 + 32 * g + pt) * 4 : reinterpret_cast<const unsigned *>(p.sh7));
-#pragma unroll
-        for (int g = 0; g < NP; ++g)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) pf[g][t].m[s] = p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h];
-        __builtin_amdgcn_sched_barrier(0);
-        reinterpret_cast<vec4 *>(sh6)[lane] = lo;
-        reinterpret_cast<vec4 *>(sh6)[64 + lane] = hi;
-        reinterpret_cast<vec4 *>(sh6 + kSh7)[lane] = c7;
-        reinterpret_cast<vec4 *>(sh6 + kSh8)[lane] = c89;           // (conv8's 128 shifts, then conv9's)
-        reinterpret_cast<vec4 *>(sh6 + kW10)[lane] = c10;
-        if (lane < 2) sh6[kB10 + lane] = cb10;
-#pragma unroll
-        for (int g = 0; g < NP; ++g) reinterpret_cast<uvec4 *>(keep_w)[g * 64 + lane] = keep[g];
-    }
-    const float *sh7 = sh6 + kSh7, *sh8 = sh6 + kSh8, *sh9 = sh6 + kSh9, *w10 = sh6 + kW10;
-
-    FPN_TSTAMP(1);
+    const int pt = lane & 31, h = lane >> 5;
+    const float *sh7 = sh6 + TailLds::kSh7, *sh8 = sh6 + TailLds::kSh8, *sh9 = sh6 + TailLds::kSh9, *w10 = sh6 + TailLds::kW10;
+    constexpr int kB10 = TailLds::kB10;
+    (void)stamp;
     Act a7[NP][8];
     {
         floatx16 acc7[P][2][NP];
@@ -1508,6 +1469,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     layer_t_acc<NP, 8, 4, Order::kFused % Feed::kDepth>(a8, a7, ws, sh8, feed, h);
     FPN_TSTAMP(5);
     ws += U8 * kUnitVecs;
+    between();       // (the caller's loads for its next round: conv9 and conv10 are time enough for them to arrive)
     layer_t_acc<NP, 4, 4, (Order::kFused + U8) % Feed::kDepth>(a9, a8, ws, sh9, feed, h);
     FPN_TSTAMP(6);
 
@@ -1515,7 +1477,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     for (int g = 0; g < NP; ++g) {
         // Monte-Carlo dropout before the head (models/FPointNet_Bayes.py:92): bit c of word j
         // of the point's mask keeps channel 32 j + c, kept activations count twice
-        if (p.drop) {
+        if (drop) {
             const uint4 keep = keep_w[g * 64 + lane];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1552,13 +1514,195 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
         float s0 = s01[g][0], s1 = s01[g][1];
         s0 += __shfl_xor(s0, 32);
         s1 += __shfl_xor(s1, 32);
-        if (h == 0) *reinterpret_cast<float2 *>(p.logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + b10[0], s1 + b10[1]);
+        if (h == 0) *reinterpret_cast<float2 *>(logits + (row0 + 32 * g + pt) * 2) = make_float2(s0 + b10[0], s1 + b10[1]);
     }
+}
+
+template <int NP, int P, class Feed>
+__global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const TailParams pin)
+{
+    using Order = TailOrder<P>;
+    static_assert(NP <= P, "a tile's riders need one unit per point group");
+    const unsigned lane = threadIdx.x & 63;
+    const int pt = lane & 31, h = lane >> 5;
+    const long row0 = ((long)logical_block(pin.copy_vecs) * kWaves + (threadIdx.x >> 6)) * (32 * NP);
+    // conv6's shifts - the frustum's row of 512 floats - wait in the wave's OWN piece of LDS (each wave reads only
+    // what it wrote: no barrier) and come back a chunk's two tiles at a time, one unit before the MFMAs that
+    // start from them
+    // The other constants of the wave's layers wait there too (conv7's, conv8's and conv9's shifts, conv10's
+    // matrix, behind the 512 floats of conv6: see stage_consts; read from memory they cost 6 % of the kernel).
+    constexpr int kSh7 = TailLds::kSh7, kSh8 = TailLds::kSh8, kW10 = TailLds::kW10, kB10 = TailLds::kB10;
+    __shared__ float shift6[kWaves][TailLds::kFloats];
+    // two passes: the first pass's half of conv7's output (64 registers of operand fragments for two point
+    // groups) has nothing to do during the second pass and waits in the wave's own piece of LDS as well
+    // (vector v of a lane at [v][lane]: consecutive 16-byte slots, no bank conflicts) - held in registers it
+    // pushed the compiler into parking values in accumulator registers and copying whole accumulator tiles around
+    constexpr bool kPark = Order::kPasses == 2;
+    constexpr int kParkVecs = NP * P * 2 * 2;        // point groups x tiles of a pass x fragments
+    __shared__ bf16x8 park7[kPark ? kWaves * kParkVecs * 64 : 1];
+    if (row0 >= pin.rows) return;       // (never with a cooperative feed: the host launches it on full workgroups only)
+    TailParams p = pin;
+    if (pin.copy_vecs) {
+        const size_t f = scalar_index(row0 / pin.n);
+        p.ws += f * pin.copy_vecs;
+        p.w10 += f * (128 * 2);
+    }
+    const bf16x8 *ws = p.ws;
+#ifdef FPN_TAIL_STAMPS      // timing-only build: cycle stamps of one wave into the first logits (wrong results)
+    long long stamp[8];
+    stamp[0] = clock64();
+#endif
+    Feed feed;
+    feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, feed_ring<Feed>(), ws);
+    bf16x8 *park = park7 + (kPark ? (threadIdx.x >> 6) * (kParkVecs * 64) + lane : 0);
+
+    // the opening's loads, all requested before the first LDS write (a write right behind its load would make
+    // the wave wait there for everything asked so far, and ask for the rest only then): the conv6 shifts of
+    // the frustum, the later layers' constants, the points' dropout bits - wanted at the very end: requested
+    // there, they would be waited for with nothing left to compute - and conv6's operands
+    float *sh6 = shift6[threadIdx.x >> 6];
+    __shared__ uint4 keep_bits[kWaves][NP][64];
+    uint4 *keep_w = keep_bits[threadIdx.x >> 6][0];
+    Act pf[NP][2];
+    {
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
+        const vec4 *src = reinterpret_cast<const vec4 *>(p.gshift + (row0 / p.n) * 512);   // (a wave's points lie in one frustum)
+        const vec4 lo = src[lane], hi = src[64 + lane];
+        const vec4 c7 = reinterpret_cast<const vec4 *>(p.sh7)[lane];
+        const vec4 c89 = reinterpret_cast<const vec4 *>(lane < 32 ? p.sh8 : p.sh9)[lane & 31];
+        const vec4 c10 = reinterpret_cast<const vec4 *>(p.w10)[lane];
+        const float cb10 = p.b10[lane & 1];
+        // (without dropout the same loads read the start of conv7's shifts instead, and nothing reads what they
+        // put in LDS: a branch round them made the compiler wait for every load before it on the other path)
+        uvec4 keep[NP];
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+            keep[g] = *reinterpret_cast<const uvec4 *>(p.drop ? p.drop + (row0 + 32 * g + pt) * 4 : reinterpret_cast<const unsigned *>(p.sh7));
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) pf[g][t].m[s] = p.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h];
+        __builtin_amdgcn_sched_barrier(0);
+        reinterpret_cast<vec4 *>(sh6)[lane] = lo;
+        reinterpret_cast<vec4 *>(sh6)[64 + lane] = hi;
+        reinterpret_cast<vec4 *>(sh6 + kSh7)[lane] = c7;
+        reinterpret_cast<vec4 *>(sh6 + kSh8)[lane] = c89;           // (conv8's 128 shifts, then conv9's)
+        reinterpret_cast<vec4 *>(sh6 + kW10)[lane] = c10;
+        if (lane < 2) sh6[kB10 + lane] = cb10;
+#pragma unroll
+        for (int g = 0; g < NP; ++g) reinterpret_cast<uvec4 *>(keep_w)[g * 64 + lane] = keep[g];
+    }
+    FPN_TSTAMP(1);
+#ifdef FPN_TAIL_STAMPS
+    long long *stamps = stamp;
+#else
+    long long *stamps = nullptr;
+#endif
+    tail_round<NP, P>(pf, sh6, keep_w, p.drop != nullptr, park, ws, feed, p.logits, row0, lane, stamps, [] {});
 #ifdef FPN_TAIL_STAMPS
     stamp[7] = clock64();
     if (blockIdx.x == gridDim.x / 2 + 8 && threadIdx.x == 64)
         for (int i = 0; i < 8; ++i) reinterpret_cast<long long *>(p.logits)[32 + i] = stamp[i];
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// The fused tail with a WORKGROUP PER FRUSTUM (or fewer workgroups that walk the frustums), as the head's
+// seg_head_frustum_bf16_kernel: a wave's opening - constants into LDS, the ring's first units, conv6's operands,
+// all from memory with nothing else on the SIMD - is 2.3 k of the 45 k cycles of a round.  Here a wave takes
+// every kWaves-th round of 32 NP points of one frustum: the constants are staged once per frustum, the ring wraps
+// to the units the next round consumes first (TailWrapFeedT), and the next round's operands and dropout bits are
+// requested before conv9 and have arrived when conv10 is done.  Same arithmetic per point as
+// seg_tail_fused_bf16_kernel: same bits.  Needs n % (kWaves * 32 NP) == 0.
+// ---------------------------------------------------------------------------
+template <int NP, int P>
+__global__ __launch_bounds__(64 * kWaves) void seg_tail_walk_bf16_kernel(const TailParams pin)
+{
+    using Order = TailOrder<P>;
+    using Feed = TailWrapFeedT<kRing>;
+    static_assert(NP <= P && (Order::kFused + units_of(256, 128) + units_of(128, 128)) % kRing == 0,
+                  "the ring's slots must come round with the stream");
+    constexpr int kRound = kWaves * 32 * NP;
+    constexpr int kUnits = Order::kStream + units_of(256, 128) + units_of(128, 128);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    __shared__ float shift6[kWaves][TailLds::kFloats];
+    constexpr bool kPark = Order::kPasses == 2;
+    constexpr int kParkVecs = NP * P * 2 * 2;
+    __shared__ bf16x8 park7[kPark ? kWaves * kParkVecs * 64 : 1];
+    __shared__ uint4 keep_bits[kWaves][NP][64];
+    float *sh6 = shift6[wave];
+    uint4 *keep_w = keep_bits[wave][0];
+    bf16x8 *park = park7 + (kPark ? wave * (kParkVecs * 64) + lane : 0);
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
+    const long frustums = pin.rows / pin.n;
+    Feed feed;
+#pragma unroll
+    for (int i = 0; i < kRing; ++i) feed.first4[i] = Order::pos(i);
+
+    auto request = [&](Act (&pf)[NP][2], uvec4 (&keep)[NP], long row0) {     // a round's inputs (unconditional loads)
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+            keep[g] = *reinterpret_cast<const uvec4 *>(pin.drop ? pin.drop + (row0 + 32 * g + pt) * 4 : reinterpret_cast<const unsigned *>(pin.sh7));
+#pragma unroll
+        for (int g = 0; g < NP; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) pf[g][t].m[s] = pin.point_feat[(row0 + 32 * g + pt) * 8 + (2 * t + s) * 2 + h];
+    };
+
+#pragma unroll 1
+    for (long f = gridDim.x == frustums ? (long)logical_block(pin.copy_vecs) : (long)blockIdx.x; f < frustums; f += gridDim.x) {
+        const bf16x8 *ws = pin.ws + (pin.copy_vecs ? (size_t)f * pin.copy_vecs : 0);
+        const float *w10g = pin.w10 + (pin.copy_vecs ? (size_t)f * (128 * 2) : 0);
+        feed.base = ws;
+        feed.end = ws + (size_t)kUnits * kUnitVecs;
+        feed.start_at([&](auto I) { return ws + (size_t)Order::pos(decltype(I)::value) * kUnitVecs; }, lane, nullptr, ws);
+        long row0 = f * pin.n + (long)wave * (32 * NP);
+        const long row_end = (f + 1) * pin.n;
+        Act pf[NP][2];
+        {
+            const vec4 *src = reinterpret_cast<const vec4 *>(pin.gshift + f * 512);
+            const vec4 lo = src[lane], hi = src[64 + lane];
+            const vec4 c7 = reinterpret_cast<const vec4 *>(pin.sh7)[lane];
+            const vec4 c89 = reinterpret_cast<const vec4 *>(lane < 32 ? pin.sh8 : pin.sh9)[lane & 31];
+            const vec4 c10 = reinterpret_cast<const vec4 *>(w10g)[lane];
+            const float cb10 = pin.b10[lane & 1];
+            uvec4 keep[NP];
+            request(pf, keep, row0);
+            __builtin_amdgcn_sched_barrier(0);
+            reinterpret_cast<vec4 *>(sh6)[lane] = lo;
+            reinterpret_cast<vec4 *>(sh6)[64 + lane] = hi;
+            reinterpret_cast<vec4 *>(sh6 + TailLds::kSh7)[lane] = c7;
+            reinterpret_cast<vec4 *>(sh6 + TailLds::kSh8)[lane] = c89;
+            reinterpret_cast<vec4 *>(sh6 + TailLds::kW10)[lane] = c10;
+            if (lane < 2) sh6[TailLds::kB10 + lane] = cb10;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) reinterpret_cast<uvec4 *>(keep_w)[g * 64 + lane] = keep[g];
+        }
+#pragma unroll 1
+        for (;;) {
+            const long next = row0 + kRound;
+            const bool more = next < row_end;
+            Act pfn[NP][2];
+            uvec4 keepn[NP];
+            tail_round<NP, P>(pf, sh6, keep_w, pin.drop != nullptr, park, ws, feed, pin.logits, row0, lane, nullptr,
+                              [&] { request(pfn, keepn, more ? next : row0); });
+            if (!more) break;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                reinterpret_cast<uvec4 *>(keep_w)[g * 64 + lane] = keepn[g];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) pf[g][t] = pfn[g][t];
+            }
+            row0 = next;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2667,8 +2811,10 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
     p.copy_vecs = copy_vecs;
     p.drop = reinterpret_cast<const unsigned *>(drop_mask);
     // FPN_BF16_TAIL: "layers" = the layer-by-layer kernel (the twin the tests compare with), "fused1" / "fused2" =
-    // conv6 interleaved with conv7, one / two point groups per wave; default: fused2 where a frustum holds whole
-    // 64-point groups, else fused1
+    // conv6 interleaved with conv7, one / two point groups per wave, "walk2" = fused2 with a workgroup per frustum
+    // (or per CU, walking the frustums; FPN_BF16_TAIL_GRID = another number of workgroups) where frustums hold
+    // whole rounds of 256 points; default: walk2 once there is a frustum per CU and all frustums share one stream,
+    // else fused2 where a frustum holds whole 64-point groups, else fused1
     const char *form = std::getenv("FPN_BF16_TAIL");
     const std::string f = form ? form : "";
     if (f == "layers") {
@@ -2679,6 +2825,17 @@ int fpn_v1_seg_tail_bf16(long rows, int n, const void *point_feat, const float *
         return check_launch("fpn_v1_seg_tail_bf16");
     }
     const int np = (f == "fused1" || n % 64 != 0) ? 1 : 2;
+    const long frustums = rows / n;
+    const int cus = current_device_cus();
+    // (not by default with a stream per frustum copy: a copy's stream is then read by ONE workgroup, four times in
+    // a row and out of a cache that 255 other copies pass through meanwhile, instead of by four workgroups side by
+    // side - 2.29 against 1.72 ms for 4096 copies)
+    if (np == 2 && n % (kWaves * 64) == 0 && f != "fused2" && (f == "walk2" || (copy_vecs == 0 && cus > 0 && frustums >= cus))) {
+        const char *ge = std::getenv("FPN_BF16_TAIL_GRID");
+        const long grid = ge && std::atol(ge) > 0 ? std::min(frustums, std::atol(ge)) : (cus > 0 && frustums >= 2 * cus) ? cus : frustums;
+        hipLaunchKernelGGL((seg_tail_walk_bf16_kernel<2, 2>), dim3((unsigned)grid), dim3(64 * kWaves), 0, as_stream(stream), p);
+        return check_launch("fpn_v1_seg_tail_bf16");
+    }
     const bool coop = use_coop(rows, np, copy_vecs, n);
     if (np == 2) {      // two point groups per wave: conv7 in two passes of two pairs (all eight tiles' accumulators
                         // for 64 points are the whole accumulator file: the compiler then spills)

@@ -260,9 +260,12 @@ def test_bf16_tail_forms_agree_bit_for_bit(device, monkeypatch, B, N, dropout):
     in the same order, so the logits - and everything after them - are the same bits; shared
     stream (plain v1) and one stream per frustum copy (Flipout, with the dropout bits).
     96- and 160-point frustums have no whole 64-point groups: the two-group form falls back
-    to one group there, 13 x 96 and 3 x 160 also leave workgroups partly filled."""
+    to one group there, 13 x 96 and 3 x 160 also leave workgroups partly filled.  "walk2": the
+    two-group form with workgroups that walk a frustum in rounds of 256 points and frustum
+    after frustum (where a frustum holds whole rounds; else it is fused2 / fused1 again)."""
     from fpn import bayes, plan, synthetic, variables
-    forms = ("layers", "fused1", "fused2")
+    forms = ("layers", "fused1", "fused2", "walk2")
+    monkeypatch.setenv("FPN_BF16_TAIL_GRID", "3")        # walk2: three workgroups take the frustums in turn
     # Flipout: per-copy streams
     st = variables.VariableStore(device, seed=4)
     bp = bayes.BayesPlan(st, 3, mc_dropout=dropout, precision="bf16")
