@@ -1788,6 +1788,93 @@ __global__ __launch_bounds__(64 * kWaves) void obj_chain_bf16_kernel(const ObjPa
 }
 
 // ---------------------------------------------------------------------------
+// The object-point stacks with workgroups that WALK the frustums (one stream for all frustums), as the seg
+// head's and tail's: obj_chain_bf16_kernel's waves live for one round of 32 NP points and open every round with
+// a trip to memory - the first weight units, the first layer's matrix and constants, the layers' shifts, the
+// points - which is a fifth of a T-Net round.  Here the first layer's operands, the shifts (one LDS copy for
+// the workgroup) and the ring are set up once per workgroup; the waves take every kWaves-th round of a frustum
+// and then the next frustum, over a wrapping ring; the next round's points are requested as soon as this
+// round's have been multiplied; a frustum's maxima meet in LDS and leave with one atomic per channel.  Same
+// arithmetic per point as obj_chain_bf16_kernel: same bits.  Needs m % (kWaves * 32 NP) == 0.
+// ---------------------------------------------------------------------------
+template <bool BOX, int NP>
+__global__ __launch_bounds__(64 * kWaves) void obj_chain_walk_bf16_kernel(const ObjParams p)
+{
+    using Feed = WrapRingFeedT<kRing>;
+    constexpr int kRound = kWaves * 32 * NP, C = BOX ? 512 : 256;
+    constexpr int U2 = units_of(128, 128), U3 = units_of(128, 256), U4 = BOX ? units_of(256, 512) : 0, U = U2 + U3 + U4;
+    static_assert(U % kRing == 0, "the ring's slots must come round with the stream");
+    constexpr int kConsts = 128 + 256 + (BOX ? 512 : 0);
+    static_assert(kConsts / 4 <= 64 * kWaves, "one vector of constants a thread");
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    __shared__ int lmax[C];
+    __shared__ float oconst[kConsts];
+    const long frustums = p.rows / p.m;
+
+    Feed feed;
+    feed.start(p.ws, lane, nullptr);
+    feed.end = p.ws + (size_t)U * kUnitVecs;
+    feed.len = (long)U * kUnitVecs;
+    FirstLayer<4, 4> first;
+    first.load(p.w1, 3, p.sc1, p.sh1, lane, h);
+    // a round's points minus the frustum's delta (unconditional loads: without a delta the points stand in)
+    auto request = [&](float (&x)[NP][4], long row0, long frustum) {
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const float *src = p.obj + (row0 + 32 * g + pt) * 3;
+            const float *dl = p.delta ? p.delta + frustum * 3 : src;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float v = src[k], d = dl[k];
+                x[g][k] = p.delta ? v - d : v;
+            }
+            x[g][3] = 0.f;
+        }
+    };
+    long f = blockIdx.x;
+    float x[NP][4];
+    request(x, (f < frustums ? f : 0) * p.m + (long)wave * (32 * NP), f < frustums ? f : 0);
+    {
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        const int k = (int)threadIdx.x < kConsts / 4 ? (int)threadIdx.x : 0;      // sh2's 32 vectors, sh3's 64, sh4's 128
+        const float *base = k < 32 ? p.sh2 : k < 96 || !BOX ? p.sh3 - 128 : p.sh4 - 384;
+        const vec4 v = reinterpret_cast<const vec4 *>(base)[k];
+        __builtin_amdgcn_sched_barrier(0);
+        if ((int)threadIdx.x < kConsts / 4) reinterpret_cast<vec4 *>(oconst)[threadIdx.x] = v;
+    }
+    const float *sh2 = oconst, *sh3 = oconst + 128, *sh4 = oconst + 384;
+    const bf16x8 *ws = p.ws;
+
+#pragma unroll 1
+    for (; f < frustums; f += gridDim.x) {
+        for (int i = threadIdx.x; i < C; i += 64 * kWaves) lmax[i] = 0;
+        __syncthreads();        // (also: the constants are there; the flush before read only what this thread clears)
+#pragma unroll 1
+        for (int r0 = (int)wave * (32 * NP); r0 < p.m; r0 += kRound) {
+            Act a1[NP][4], a2[NP][4];
+            first.apply(a1, x, h);
+            {       // the next round's points: of this frustum, or the first of the workgroup's next one
+                const bool here = r0 + kRound < p.m;
+                const long fn = here ? f : (f + gridDim.x < frustums ? f + gridDim.x : f);
+                request(x, fn * p.m + (here ? r0 + kRound : (int)wave * (32 * NP)), fn);
+            }
+            layer_t_acc<NP, 4, 4, 0>(a2, a1, ws, sh2, feed, h);
+            if constexpr (!BOX) {
+                layer_max<NP, 4, 8, U2 % kRing>(a2, ws + U2 * kUnitVecs, sh3, lmax, feed, lane);
+            } else {
+                Act a3[NP][8];
+                layer_t_acc<NP, 4, 8, U2 % kRing>(a3, a2, ws + U2 * kUnitVecs, sh3, feed, h);
+                layer_max<NP, 8, 16, (U2 + U3) % kRing>(a3, ws + (U2 + U3) * kUnitVecs, sh4, lmax, feed, lane);
+            }
+        }
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < C; ch += 64 * kWaves)
+            atomicMax(reinterpret_cast<int *>(p.gmax + f * p.ldg + ch), lmax[ch]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Set-abstraction module (models/pointnet_util.py:86-195) as one kernel, as
 // sa_chain_kernel of chain_reg.hip; a wave takes 32 NP consecutive samples of one ball.
 // NJF > 0: the gathered point features are the first layer's operand tiles (converted to
@@ -2873,6 +2960,20 @@ int fpn_v1_obj_chain_bf16(long rows, int m, int box, const float *obj, const flo
     const int np = groups_per_wave(m);
     const dim3 grid = grid_for(rows, np), block(64 * kWaves);
     hipStream_t st = as_stream(stream);
+    // FPN_BF16_OBJ: "round" = a wave per round of points (any shape), "walk" = workgroups that walk the frustums
+    // (one stream for all frustums, whole rounds of 256 points per frustum; FPN_BF16_OBJ_GRID = their number);
+    // default: walk from two frustums per CU on
+    const char *form = std::getenv("FPN_BF16_OBJ");
+    const std::string of = form ? form : "";
+    const long frustums = rows / m;
+    const int cus = current_device_cus();
+    if (np == 2 && copy_vecs == 0 && m % (kWaves * 64) == 0 && of != "round" && (of == "walk" || (cus > 0 && frustums >= 2 * cus))) {
+        const char *ge = std::getenv("FPN_BF16_OBJ_GRID");
+        const long g = ge && std::atol(ge) > 0 ? std::min(frustums, std::atol(ge)) : (cus > 0 ? std::min<long>(frustums, cus) : frustums);
+        if (box) hipLaunchKernelGGL((obj_chain_walk_bf16_kernel<true, 2>), dim3((unsigned)g), block, 0, st, p);
+        else hipLaunchKernelGGL((obj_chain_walk_bf16_kernel<false, 2>), dim3((unsigned)g), block, 0, st, p);
+        return check_launch("fpn_v1_obj_chain_bf16");
+    }
     if (box && np == 2) hipLaunchKernelGGL((obj_chain_bf16_kernel<true, 2>), grid, block, 0, st, p);
     else if (box) hipLaunchKernelGGL((obj_chain_bf16_kernel<true, 1>), grid, block, 0, st, p);
     else if (np == 2) hipLaunchKernelGGL((obj_chain_bf16_kernel<false, 2>), grid, block, 0, st, p);

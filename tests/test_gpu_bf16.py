@@ -348,6 +348,35 @@ def test_bf16_head_forms_agree_bit_for_bit(device, monkeypatch, B, N, C):
         assert torch.equal(res["round"][k], res["frustum"][k]), k
 
 
+@pytest.mark.parametrize("B,M", [(5, 512), (7, 256), (2, 1024)])
+def test_bf16_object_stack_forms_agree_bit_for_bit(device, monkeypatch, B, M):
+    """The T-Net and box stacks over the object points with workgroups that walk the frustums
+    (first-layer operands, shifts and ring set up once; three workgroups take the frustums in
+    turn) against the kernel whose waves take one round each: the same arithmetic per point, so
+    the frustum maxima are the same bits - with and without the centre delta, on top of a
+    running maximum in the output."""
+    from fpn import ops, plan, variables
+    st = variables.VariableStore(device, seed=21)
+    plan.init_variables(st, 4, True)
+    st.randomize_batch_norm(22)
+    net = plan.V1Plan(st, 4, True, precision="bf16")
+    rng = np.random.RandomState(B * M)
+    obj = dev(rng.standard_normal((B * M, 3)).astype(np.float32), device)
+    delta = dev(rng.standard_normal((B, 3)).astype(np.float32), device)
+    monkeypatch.setenv("FPN_BF16_OBJ_GRID", "3")
+    for box, ws, consts, width in ((False, net._tnet_ws, net._tnet_consts, 256), (True, net._box_ws, net._box_consts, 512)):
+        for d in (None, delta):
+            got = {}
+            for form in ("round", "walk"):
+                monkeypatch.setenv("FPN_BF16_OBJ", form)
+                out = torch.zeros((B, width + 3), device=device)
+                out[0, :width] = 0.25                    # a running maximum that some channels stay below
+                ops.v1_obj_chain_bf16(obj, M, box, d, ws, consts, out)
+                got[form] = out
+            assert float(got["round"][1:, :width].abs().max()) > 0
+            assert torch.equal(got["round"], got["walk"]), (box, d is not None)
+
+
 @pytest.mark.parametrize("rows,cin,cout,pool,gb", [
     (300, 67, 59, 0, 0), (4096, 448, 128, 0, 0), (1024, 643, 200, 32, 0), (2048, 256, 1024, 64, 0),
     (1536, 128, 256, 128, 0), (2048, 640, 128, 0, 256), (4096, 256, 512, 512, 0), (640, 130, 128, 0, 5),
