@@ -379,7 +379,9 @@ class BayesPlan:
 
         # segmentation net (FPointNet_Bayes.py:71-96): conv1..conv5 + max-pool, then
         # conv6..conv10 with the frustum-constant part of conv6 as a per-frustum shift
-        gcat = torch.zeros((b, 1024 + 3), dtype=torch.float32, device=dev)
+        # (the three [pooled features | one-hot] rows of a copy in ONE zeroed buffer, as in V1Plan._forward_chunk)
+        cat = torch.zeros((b, 1028 + 260 + 516), dtype=torch.float32, device=dev)
+        gcat, tcat, bcat = cat[:, :1024 + 3], cat[:, 1028:1028 + 256 + 3], cat[:, 1288:1288 + 512 + 3]
         gcat[:, 1024:] = one_hot
         point_feat = torch.empty((b * n, 64), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         if bf16:
@@ -424,7 +426,6 @@ class BayesPlan:
         obj2d = obj.reshape(b * m, 3)
 
         # T-Net (FPointNet_Bayes.py:120-137)
-        tcat = torch.zeros((b, 256 + 3), dtype=torch.float32, device=dev)
         tcat[:, 256:] = one_hot
         obj_chain(("conv-reg1-stage1", "conv-reg2-stage1", "conv-reg3-stage1"), False, None, tcat)
         t = conv(tcat, "fc1-stage1", 1)
@@ -435,7 +436,6 @@ class BayesPlan:
             center_delta = self._plain(t, "fc3-stage1", out=outs.get("center_delta"))
 
         # box net (FPointNet_Bayes.py:99-117); the kernel subtracts center_delta on load
-        bcat = torch.zeros((b, 512 + 3), dtype=torch.float32, device=dev)
         bcat[:, 512:] = one_hot
         obj_chain(("conv-reg1", "conv-reg2", "conv-reg3", "conv-reg4"), True,
                   center_delta if self.recentre_box_input else None, bcat)

@@ -192,12 +192,18 @@ class V1Plan:
         x = pc.reshape(rows, c)
 
         # --- instance segmentation net (frustum_pointnets_v1.py:20-90) -------------
-        gcat = torch.empty((b, 1024 + 3), dtype=torch.float32, device=dev)
-        gcat[:, 1024:] = one_hot                                        # concat one-hot :64
         bf16 = self.precision == "bf16"
         if self.chain:
+            # the three [pooled features | one-hot] rows of a frustum lie in ONE zeroed buffer (the chain kernels
+            # accumulate their maxima in place): one fill instead of three, and every part starts on a 16-byte
+            # boundary with a row stride of whole 16-byte groups, which the dense layers read as vectors
+            cat = torch.zeros((b, 1028 + 260 + 516), dtype=torch.float32, device=dev)
+            gcat, tcat, bcat = cat[:, :1024 + 3], cat[:, 1028:1028 + 256 + 3], cat[:, 1288:1288 + 512 + 3]
+        else:
+            gcat = torch.empty((b, 1024 + 3), dtype=torch.float32, device=dev)
+        gcat[:, 1024:] = one_hot                                        # concat one-hot :64
+        if self.chain:
             point_feat = torch.empty((rows, 64), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
-            gcat[:, :1024] = 0                    # the head kernel accumulates the maximum in place
             if bf16:
                 ops.v1_seg_head_bf16(x, n, self._head_ws, self._head_consts, point_feat, gcat)
             else:
@@ -234,11 +240,11 @@ class V1Plan:
         mask, mean, sel, obj = ops.mask_gather(pc, logits, m)
 
         # --- T-Net (model_util.py:322-357) ---------------------------------------------
-        tcat = torch.empty((b, 256 + 3), dtype=torch.float32, device=dev)
+        if not self.chain:
+            tcat = torch.empty((b, 256 + 3), dtype=torch.float32, device=dev)
         tcat[:, 256:] = one_hot
         obj2d = obj.reshape(b * m, 3)
         if self.chain:
-            tcat[:, :256] = 0
             if bf16:
                 ops.v1_obj_chain_bf16(obj2d, m, False, None, self._tnet_ws, self._tnet_consts, tcat)
             else:
@@ -253,11 +259,11 @@ class V1Plan:
         stage1_center = center_delta + mean                              # frustum_pointnets_v1.py:173
 
         # --- box estimation net (frustum_pointnets_v1.py:93-138) ------------------------
-        bcat = torch.empty((b, 512 + 3), dtype=torch.float32, device=dev)
+        if not self.chain:
+            bcat = torch.empty((b, 512 + 3), dtype=torch.float32, device=dev)
         bcat[:, 512:] = one_hot
         if self.chain:
             # the kernel subtracts center_delta while loading the tile (:176-177)
-            bcat[:, :512] = 0
             if bf16:
                 ops.v1_obj_chain_bf16(obj2d, m, True, center_delta, self._box_ws, self._box_consts, bcat)
             else:
