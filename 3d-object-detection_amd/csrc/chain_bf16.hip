@@ -403,18 +403,7 @@ __device__ __forceinline__ void load_const(TileConst &c, const float *__restrict
 // behind the weight units requested last - loads return in order, so waiting for it means waiting for the
 // whole read-ahead of the weight ring; LDS reads are counted apart from the weight loads.  N floats (a
 // multiple of 4), src 16-byte aligned.
-template <int N>
-__device__ __forceinline__ void stage_consts(float *dst, const float *__restrict__ src, unsigned lane)
-{
-    static_assert(N % 4 == 0, "whole 16-byte vectors");
-#pragma unroll
-    for (int i = 0; i < (N / 4 + 63) / 64; ++i) {
-        const int v = i * 64 + (int)lane;
-        if ((N / 4) % 64 == 0 || v < N / 4) reinterpret_cast<float4 *>(dst)[v] = reinterpret_cast<const float4 *>(src)[v];
-    }
-}
-
-// The same in two steps, for a kernel's opening: request() only asks for the vectors, put() writes them to LDS.
+// In two steps, for a kernel's opening: request() only asks for the vectors, put() writes them to LDS.
 // A write placed right behind its own load makes the wave wait there - for every load asked for before it, the
 // weight ring's first units included - and only then ask for its inputs: two trips to memory one after the
 // other.  With every load of the opening requested first, the waits that follow are for one trip.
@@ -1530,7 +1519,7 @@ __global__ __launch_bounds__(64 * kWaves) void seg_tail_fused_bf16_kernel(const 
     // what it wrote: no barrier) and come back a chunk's two tiles at a time, one unit before the MFMAs that
     // start from them
     // The other constants of the wave's layers wait there too (conv7's, conv8's and conv9's shifts, conv10's
-    // matrix, behind the 512 floats of conv6: see stage_consts; read from memory they cost 6 % of the kernel).
+    // matrix, behind the 512 floats of conv6: see StagedConsts; read from memory they cost 6 % of the kernel).
     constexpr int kSh7 = TailLds::kSh7, kSh8 = TailLds::kSh8, kW10 = TailLds::kW10, kB10 = TailLds::kB10;
     __shared__ float shift6[kWaves][TailLds::kFloats];
     // two passes: the first pass's half of conv7's output (64 registers of operand fragments for two point
@@ -2681,7 +2670,7 @@ inline bool use_coop(long rows, int np, long copy_vecs, long group)
     return coop_feed() && rows % wg_rows == 0 && (copy_vecs == 0 || group % wg_rows == 0);
 }
 
-// the kernels copy their layer constants with 16-byte loads (stage_consts, load_const)
+// the kernels copy their layer constants with 16-byte loads (StagedConsts, load_const)
 inline bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 inline dim3 grid_for(long rows, int np)
