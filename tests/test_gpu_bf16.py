@@ -348,6 +348,32 @@ def test_bf16_head_forms_agree_bit_for_bit(device, monkeypatch, B, N, C):
         assert torch.equal(res["round"][k], res["frustum"][k]), k
 
 
+def test_bf16_forms_the_library_picks_at_scale_agree_with_the_round_forms(device, monkeypatch):
+    """With two frustums per CU or more the library itself takes the walking forms of the head,
+    the tail and the object-point stacks (one workgroup per CU): the whole v1 network on 640
+    frustums of 256 points with no switch set, against the same network with every kernel forced
+    to its wave-per-round form - all end points the same bits."""
+    from fpn import plan, synthetic, variables
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    B, N, C = max(640, 2 * cus + 64), 256, 4
+    st = variables.VariableStore(device, seed=31)
+    plan.init_variables(st, C, True)
+    st.randomize_batch_norm(32)
+    net = plan.V1Plan(st, C, True, precision="bf16")
+    pc, oh = synthetic.make_frustums(B, N, C, seed=33)
+    pcd, ohd = dev(pc, device), dev(oh, device)
+    for k in ("FPN_BF16_HEAD", "FPN_BF16_TAIL", "FPN_BF16_OBJ", "FPN_BF16_HEAD_GRID", "FPN_BF16_TAIL_GRID", "FPN_BF16_OBJ_GRID"):
+        monkeypatch.delenv(k, raising=False)
+    picked = {k: v.clone() for k, v in net.forward(pcd, ohd).items()}
+    monkeypatch.setenv("FPN_BF16_HEAD", "round")
+    monkeypatch.setenv("FPN_BF16_TAIL", "fused2")
+    monkeypatch.setenv("FPN_BF16_OBJ", "round")
+    forced = net.forward(pcd, ohd)
+    assert float(picked["mask_logits"].abs().max()) > 0
+    for k in forced:
+        assert torch.equal(picked[k], forced[k]), k
+
+
 @pytest.mark.parametrize("B,M", [(5, 512), (7, 256), (2, 1024)])
 def test_bf16_object_stack_forms_agree_bit_for_bit(device, monkeypatch, B, M):
     """The T-Net and box stacks over the object points with workgroups that walk the frustums
