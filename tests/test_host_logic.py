@@ -93,6 +93,12 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.fpn_v1_obj_chain_bf16(64, 32, 1, P, None, P, bad, 0, P, 512, None) == -1
     assert b"16-byte aligned" in lib.fpn_last_error_string()
     assert lib.fpn_v1_seg_head_bf16(0, 32, 4, None, None, None, 0, None, None, 1024, None) == 0
+    # Flipout signs from bits: sizes, null pointers and alignment are checked before the launch
+    assert lib.fpn_flipout_signs(0, None, None, None) == 0
+    assert lib.fpn_flipout_signs(-1, P, P, None) == -1
+    assert lib.fpn_flipout_signs(64, None, P, None) == -1
+    assert lib.fpn_flipout_signs(64, P, ctypes.c_void_p(260), None) == -1
+    assert b"aligned" in lib.fpn_last_error_string()
 
 
 def test_ball_threshold_equals_sqrt_test():
