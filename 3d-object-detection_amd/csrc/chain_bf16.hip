@@ -2614,16 +2614,26 @@ __global__ void pack_units_kernel(int cin, int cout, const float *__restrict__ w
 // converted to bf16 in the element order of pack_units_kernel.  One thread writes one
 // 16-byte vector per copy for kFlipCopies consecutive copies (blockIdx.y): mean and
 // perturbation are read once per group, only the signs differ from copy to copy.
-// (Bound by its writes: 3.6 TB/s of 16-byte vectors, 1 KB a wave and copy, 4.9 GB a pass of 4096 copies.  The
-// copies' input signs read as two vectors instead of eight scalars, and all eight copies' signs requested before
-// the first product, each measured the same 1.34 ms a pass.)
+// (4.9 GB a pass of 4096 copies, 1 KB a wave and copy; a plain fill writes 6.9 TB/s on this chip.  What kept the
+// kernel at 3.6 TB/s was not its stores but where its float signs come from - see SignBits.)
 constexpr int kFlipCopies = 8;
 
+// BITS: the signs are one bit each (set = +1) in the words of `bits`: copy f's input sign k at bit
+// in0 + f * ld_in + k, its output sign at bit out0 + f * ld_out + col (in0, ld_in multiples of 4: a lane's four
+// consecutive input signs lie in one word).  The float signs of a pass of 4096 copies are 164 MB that come from
+// memory in 64-byte pieces between the kernel's writes - with every copy reading the SAME rows the kernel ran in
+// 0.94 instead of 1.28 ms a pass; as bits they are 5 MB and stay in the L2.
+struct SignBits {
+    const unsigned *bits;
+    long in0, out0;
+};
+
+template <bool BITS>
 __global__ __launch_bounds__(256) void flipout_units_kernel(long copies, int cin, int cout, const float *__restrict__ w_mean,
                                                             const float *__restrict__ w_delta, int frustums_per_delta,
                                                             long delta_stride, const float *__restrict__ sign_in,
                                                             int ld_in, const float *__restrict__ sign_out, int ld_out,
-                                                            bf16x8 *__restrict__ dst, long copy_vecs, long copy0)
+                                                            bf16x8 *__restrict__ dst, long copy_vecs, long copy0, SignBits sb_)
 {
     const long f0 = copy0 + (long)blockIdx.y * kFlipCopies;
     const int nf = (int)min((long)kFlipCopies, copies - f0);
@@ -2636,20 +2646,60 @@ __global__ __launch_bounds__(256) void flipout_units_kernel(long copies, int cin
     float m[8], d[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = w_mean[(long)(k0 + 8 * (e >> 2) + (e & 3)) * cout + col];
-    long sample = -1;
-    for (int c = 0; c < nf; ++c) {
+    // (all of the group's signs are requested before its first store: loads behind stores wait for the stores)
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    vec4 sa[kFlipCopies], sb[kFlipCopies];
+    float so[kFlipCopies];
+    if constexpr (BITS) {
+        unsigned wa[kFlipCopies], wb[kFlipCopies], wo[kFlipCopies];
+#pragma unroll
+        for (int c = 0; c < kFlipCopies; ++c) {
+            const long f = f0 + (c < nf ? c : nf - 1);
+            const long ia = sb_.in0 + f * ld_in + k0, io = sb_.out0 + f * ld_out + col;
+            wa[c] = sb_.bits[ia >> 5] >> (ia & 31);
+            wb[c] = sb_.bits[(ia + 8) >> 5] >> ((ia + 8) & 31);
+            wo[c] = sb_.bits[io >> 5] >> (io & 31);
+        }
+#pragma unroll
+        for (int c = 0; c < kFlipCopies; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[c][i] = (wa[c] >> i) & 1u ? 1.f : -1.f;
+                sb[c][i] = (wb[c] >> i) & 1u ? 1.f : -1.f;
+            }
+            so[c] = wo[c] & 1u ? 1.f : -1.f;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < kFlipCopies; ++c) {
+            const long f = f0 + (c < nf ? c : nf - 1);
+            const float *si = sign_in + f * ld_in + k0;
+            sa[c] = *reinterpret_cast<const vec4 *>(si);
+            sb[c] = *reinterpret_cast<const vec4 *>(si + 8);
+            so[c] = sign_out[f * ld_out + col];
+        }
+    }
+    long sample = f0 / frustums_per_delta, bound = (sample + 1) * frustums_per_delta;
+    {
+        const float *dw = w_delta + sample * delta_stride;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = dw[(long)(k0 + 8 * (e >> 2) + (e & 3)) * cout + col];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < kFlipCopies; ++c) {
+        if (c >= nf) break;
         const long f = f0 + c;
-        if (f / frustums_per_delta != sample) {
-            sample = f / frustums_per_delta;
+        if (f >= bound) {
+            ++sample;
+            bound += frustums_per_delta;
             const float *dw = w_delta + sample * delta_stride;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d[e] = dw[(long)(k0 + 8 * (e >> 2) + (e & 3)) * cout + col];
         }
-        const float so = sign_out[f * ld_out + col];
-        const float *si = sign_in + f * ld_in + k0;
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaf(d[e], si[8 * (e >> 2) + (e & 3)] * so, m[e]);
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaf(d[e], (e < 4 ? sa[c][e] : sb[c][e - 4]) * so[c], m[e]);
         dst[f * copy_vecs + v] = o;
     }
 }
@@ -2811,11 +2861,37 @@ int fpn_flipout_stream_bf16(long copies, int cin, int cout, const float *w_mean,
     const long per_launch = 65535L * kFlipCopies;
     for (long c0 = 0; c0 < copies; c0 += per_launch) {
         const unsigned gy = (unsigned)((std::min<long>(per_launch, copies - c0) + kFlipCopies - 1) / kFlipCopies);
-        hipLaunchKernelGGL(flipout_units_kernel, dim3(gx, gy), dim3(256), 0, as_stream(stream), copies, cin, cout, w_mean, w_delta,
+        hipLaunchKernelGGL(flipout_units_kernel<false>, dim3(gx, gy), dim3(256), 0, as_stream(stream), copies, cin, cout, w_mean, w_delta,
                            frustums_per_delta, delta_stride, sign_in, ld_in, sign_out, ld_out,
-                           reinterpret_cast<bf16x8 *>(units), copy_vecs, c0);
+                           reinterpret_cast<bf16x8 *>(units), copy_vecs, c0, SignBits{});
     }
     return check_launch("fpn_flipout_stream_bf16");
+}
+
+int fpn_flipout_stream_bits_bf16(long copies, int cin, int cout, const float *w_mean, const float *w_delta,
+                                 int frustums_per_delta, long delta_stride, const void *bits, long in_bit0, int ld_in,
+                                 long out_bit0, int ld_out, void *units, long copy_vecs, void *stream)
+{
+    FPN_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 64 && cout % 64 == 0,
+                "flipout_stream_bits_bf16: cin (%d) must be a multiple of 32 and cout (%d) of 64", cin, cout);
+    FPN_REQUIRE(copies >= 0 && frustums_per_delta >= 1 && ld_in >= cin && ld_out >= cout &&
+                    copy_vecs >= (long)cin * cout / 8 && in_bit0 >= 0 && out_bit0 >= 0,
+                "flipout_stream_bits_bf16: bad size or stride");
+    FPN_REQUIRE(in_bit0 % 4 == 0 && ld_in % 4 == 0,
+                "flipout_stream_bits_bf16: a copy's input signs must start at a multiple of four bits (bit %ld, %d a copy)", in_bit0, ld_in);
+    if (copies == 0) return FPN_OK;
+    FPN_REQUIRE(w_mean && w_delta && bits && units, "flipout_stream_bits_bf16: null pointer");
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(bits) & 3) == 0, "flipout_stream_bits_bf16: bits must be 4-byte aligned");
+    const unsigned gx = (unsigned)((cin * cout / 8 + 255) / 256);
+    const long per_launch = 65535L * kFlipCopies;
+    const SignBits sb{static_cast<const unsigned *>(bits), in_bit0, out_bit0};
+    for (long c0 = 0; c0 < copies; c0 += per_launch) {
+        const unsigned gy = (unsigned)((std::min<long>(per_launch, copies - c0) + kFlipCopies - 1) / kFlipCopies);
+        hipLaunchKernelGGL(flipout_units_kernel<true>, dim3(gx, gy), dim3(256), 0, as_stream(stream), copies, cin, cout, w_mean, w_delta,
+                           frustums_per_delta, delta_stride, nullptr, ld_in, nullptr, ld_out,
+                           reinterpret_cast<bf16x8 *>(units), copy_vecs, c0, sb);
+    }
+    return check_launch("fpn_flipout_stream_bits_bf16");
 }
 
 int fpn_v1_seg_head_bf16(long rows, int n, int cpc, const float *pc, const void *wstream, const float *const *consts,

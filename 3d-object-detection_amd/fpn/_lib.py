@@ -69,6 +69,7 @@ SIGNATURES = {
     "fpn_chain_pad_units_bf16": [],
     "fpn_chain_pack_bf16": [_i, _i, _vp, _vp, _vp, _vp],
     "fpn_flipout_stream_bf16": [_l, _i, _i, _vp, _vp, _i, _l, _vp, _i, _vp, _i, _vp, _l, _vp],
+    "fpn_flipout_stream_bits_bf16": [_l, _i, _i, _vp, _vp, _i, _l, _vp, _l, _i, _l, _i, _vp, _l, _vp],
     "fpn_v1_seg_head_bf16": [_l, _i, _i, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp],
     "fpn_v1_seg_tail_bf16": [_l, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp],
     "fpn_v1_obj_chain_bf16": [_l, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _i, _vp],

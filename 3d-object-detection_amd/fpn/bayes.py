@@ -21,6 +21,8 @@ kernel_posterior_loc), '<scope>/rho' (tfp kernel_posterior_untransformed_scale),
 '<scope>/biases' (bias_posterior_loc, deterministic in tfp's default).
 """
 import numpy as np
+import os
+
 import torch
 
 from . import model_util, ops, plan as _plan
@@ -72,6 +74,8 @@ class Noise(dict):
     all draws of a sample block by softplus(rho) in one launch instead of one per layer."""
     eps_all = None
     offsets = None
+    sign_bits = None        # the int32 words all signs were spread from, and per scope where its signs start:
+    sign_pos = None         # sign_pos[scope] = (first input bit, bits per row, first output bit, bits per row)
 
 
 class BayesPlan:
@@ -132,10 +136,12 @@ class BayesPlan:
                              generator=generator)
         sign_all = ops.flipout_signs(bits, total_s)
         noise.eps_all, noise.offsets = eps_all, {}
+        noise.sign_bits, noise.sign_pos = bits, {}
         e = w = 0
         for scope, cin, cout in flip:
             noise.offsets[scope] = e
             ri, ro = row(scope, cin), row(scope, cout)
+            noise.sign_pos[scope] = (w, ri, w + up4(copies * ri), ro)
             si = sign_all[w:w + copies * ri].view(nsamples, batch, ri)[:, :, :cin]
             w += up4(copies * ri)
             so = sign_all[w:w + copies * ro].view(nsamples, batch, ro)[:, :, :cout]
@@ -292,6 +298,10 @@ class BayesPlan:
                               v[1][s0:s1].reshape(sp * bb, -1) if whole else v[1][s0:s1, lo:hi].reshape(sp * bb, -1),
                               v[2][s0:s1].reshape(sp * bb, -1) if whole else v[2][s0:s1, lo:hi].reshape(sp * bb, -1))
                           for k, v in noise.items()}
+                    # the same signs as bits, where the pass's copies are consecutive rows of the sign matrices
+                    if shared is not None and shared.sign_bits is not None and whole and self.precision == "bf16" \
+                            and os.environ.get("FPN_FLIPOUT_BITS", "1") != "0":
+                        nz["__bits__"] = (shared.sign_bits, s0 * b, shared.sign_pos)
                     if rep is None or rep[0] != sp:      # the repeated inputs are the same for every pass of a block
                         rep = (sp, pcs.repeat(sp, 1, 1) if sp > 1 else pcs, ohs.repeat(sp, 1) if sp > 1 else ohs)
                     dm = None if drop is None else drop[s0:s1, lo:hi].reshape(sp * bb * n, 4).contiguous()
@@ -361,11 +371,18 @@ class BayesPlan:
             scale, _ = self._fold(scope)
             return (w, dw) if scale is None else (w * scale, dw * scale)
 
+        def sign_bits(scope):          # (bits, first input bit, bits a copy, first output bit, bits a copy) or None
+            if "__bits__" not in nz:
+                return None
+            bits, row0, pos = nz["__bits__"]
+            in0, ri, out0, ro = pos[scope]
+            return (bits, in0 + row0 * ri, ri, out0 + row0 * ro, ro)
+
         def streams(scopes, first=None):           # bf16: per-copy weight streams of a kernel
             layers = [] if first is None else [first]
             for k in scopes:
                 dw, si, so = nz[k]
-                layers.append(scaled(k, st[k + "/weights"], dw) + (si, so))
+                layers.append(scaled(k, st[k + "/weights"], dw) + (si, so, sign_bits(k)))
             return ops.flipout_streams_bf16(b, layers)
 
         def obj_chain(scopes, box, delta, out):
@@ -409,7 +426,8 @@ class BayesPlan:
             w6p, dw6p = scaled("conv6", w6[:64], dw6[:, :64])
             ws, cv = streams(("conv7", "conv8", "conv9"),
                              first=(w6p, dw6p if dw6p.stride(1) == 512 and dw6p.stride(2) == 1 else dw6p.contiguous(),
-                                    si6[:, :64] if si6.stride(0) % 4 == 0 else si6[:, :64].contiguous(), so6))
+                                    si6[:, :64] if si6.stride(0) % 4 == 0 else si6[:, :64].contiguous(), so6,
+                                    sign_bits("conv6")))
             tail = [self._fold(k)[1] for k in ("conv7", "conv8", "conv9")] + [w10, shift10]
             ops.v1_seg_tail_bf16(point_feat, n, gshift, ws, ops.pointer_table(tail), logits, copy_vecs=cv,
                                  drop_mask=drop_mask)

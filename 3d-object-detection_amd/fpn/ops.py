@@ -312,7 +312,9 @@ def flipout_streams_bf16(copies, layers):
     """Per-copy weight streams of a bf16 chain kernel under Flipout: `layers` is the
     list of (w_mean (cin,cout), w_delta (S,cin,cout), sign_in (copies,>=cin), sign_out
     (copies,cout)) in the order the kernel runs them (fpn_flipout_stream_bf16 per layer).
-    Returns (stream tensor, copy_vecs)."""
+    An entry may carry a fifth item (bits int32 tensor, in_bit0, ld_in, out_bit0, ld_out): the
+    same signs as one bit each (fpn_flipout_stream_bits_bf16 - same units, read from a few
+    megabytes instead of 4 bytes a sign).  Returns (stream tensor, copy_vecs)."""
     lib = _lib.load()
     dev = layers[0][0].device
     per = sum(l[0].shape[0] * l[0].shape[1] for l in layers)
@@ -321,11 +323,24 @@ def flipout_streams_bf16(copies, layers):
     out[copies * per:].zero_()
     off = 0
     with torch.cuda.device(dev):
-        for w, dw, si, so in layers:
+        for layer in layers:
+            w, dw, si, so = layer[:4]
             cin, cout = w.shape
             s = dw.shape[0]
             if dw.dim() != 3 or copies % s != 0 or dw.stride(2) != 1 or dw.stride(1) != cout:
                 raise ValueError("w_delta must be (samples, cin, cout) with dense matrices and samples dividing %d" % copies)
+            if len(layer) > 4 and layer[4] is not None:
+                bits, in0, ldi, out0, ldo = layer[4]
+                if bits.dtype != torch.int32 or not bits.is_contiguous():
+                    raise ValueError("sign bits must be a contiguous int32 tensor")
+                if max(in0 + (copies - 1) * ldi + cin, out0 + (copies - 1) * ldo + cout) > 32 * bits.numel():
+                    raise ValueError("sign bits: the last copy's signs lie beyond the tensor")
+                _lib.check(lib.fpn_flipout_stream_bits_bf16(copies, cin, cout, _lib.ptr(w), _lib.ptr(dw), copies // s,
+                                                            dw.stride(0) if s > 1 else 0, _lib.ptr(bits), int(in0), int(ldi),
+                                                            int(out0), int(ldo), ctypes.c_void_p(out.data_ptr() + 2 * off),
+                                                            per // 8, _lib.stream_of(w)))
+                off += cin * cout
+                continue
             _lib.check(lib.fpn_flipout_stream_bf16(copies, cin, cout, _lib.ptr(w), _lib.ptr(dw), copies // s,
                                                    dw.stride(0) if s > 1 else 0, _lib.ptr(si), _ld(si), _lib.ptr(so),
                                                    _ld(so), ctypes.c_void_p(out.data_ptr() + 2 * off), per // 8,

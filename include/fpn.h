@@ -519,6 +519,18 @@ int fpn_flipout_stream_bf16(long copies, int cin, int cout, const float *w_mean,
                             int frustums_per_delta, long delta_stride, const float *sign_in, int ld_in,
                             const float *sign_out, int ld_out, void *units, long copy_vecs,
                             void *stream);
+
+/*
+ * fpn_flipout_stream_bf16 with the signs as ONE BIT each (set = +1, as fpn_flipout_signs spreads them): copy f's
+ * input sign k is bit in_bit0 + f * ld_in + k of the 32-bit words at `bits`, its output sign c bit
+ * out_bit0 + f * ld_out + c (in_bit0 and ld_in multiples of 4).  Same units, bit for bit, as the float signs
+ * give; the signs of a pass are then a few megabytes that stay in the cache instead of 4 bytes a sign read from
+ * memory between the kernel's writes.  No counterpart in the reference (its signs live inside
+ * tensorflow_probability's layers, models/FPointNet_Bayes.py:54-68).
+ */
+int fpn_flipout_stream_bits_bf16(long copies, int cin, int cout, const float *w_mean, const float *w_delta,
+                                 int frustums_per_delta, long delta_stride, const void *bits, long in_bit0, int ld_in,
+                                 long out_bit0, int ld_out, void *units, long copy_vecs, void *stream);
 /* stream: conv2, conv3, conv4, conv5; consts {w1 (cpc,64), scale1, shift1, shift2..shift5};
  * point_feat (rows,64) bf16 in an internal operand order, only meaningful to
  * fpn_v1_seg_tail_bf16; global_max as in fpn_v1_seg_head_f32. */

@@ -201,6 +201,32 @@ def test_sample_noise_layout_and_fairness(device):
     assert torch.equal(noise["dropout"], again["dropout"])
 
 
+@pytest.mark.parametrize("dropout", [False, True])
+def test_flipout_streams_from_sign_bits_are_the_same_bits(device, monkeypatch, dropout):
+    """The bf16 weight streams built from one bit per sign (fpn_flipout_stream_bits_bf16, what a plan
+    does with noise it drew itself) against the streams built from the +-1 floats spread from the same
+    bits: every end point of the whole Flipout pass the same bits.  Three samples of five frustums,
+    so the copies of a pass start at a row other than 0 in the second block."""
+    from fpn import bayes, synthetic, variables
+    st = variables.VariableStore(device, seed=41)
+    bp = bayes.BayesPlan(st, 4, mc_dropout=dropout, precision="bf16")
+    bp.CHAIN_COPIES = 10                       # two samples a pass: the second pass starts at row 10
+    S, B, N = 4, 5, 128
+    pc, oh = synthetic.make_frustums(B, N, 4, seed=42)
+    g = torch.Generator(device=device)
+    g.manual_seed(43)
+    noise = bp.sample_noise(S, B, g, N)
+    assert noise.sign_bits is not None and set(noise.sign_pos) == set(bp.flip_scopes)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FPN_FLIPOUT_BITS", flag)
+        ep = bp.forward(dev(pc, device), dev(oh, device), S, noise=noise)
+        got[flag] = {k: ep[k].clone() for k in ("mask_logits", "box_output", "stage1_center", "center")}
+    assert float(got["1"]["mask_logits"].abs().max()) > 0
+    for k in got["1"]:
+        assert torch.equal(got["1"][k], got["0"][k]), k
+
+
 def test_mc_statistics(device):
     from fpn import uncertainty
     rng = np.random.RandomState(4)

@@ -93,6 +93,12 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.fpn_v1_obj_chain_bf16(64, 32, 1, P, None, P, bad, 0, P, 512, None) == -1
     assert b"16-byte aligned" in lib.fpn_last_error_string()
     assert lib.fpn_v1_seg_head_bf16(0, 32, 4, None, None, None, 0, None, None, 1024, None) == 0
+    # Flipout streams from sign bits: a copy's input signs must start on a multiple of four bits
+    assert lib.fpn_flipout_stream_bits_bf16(8, 64, 64, P, P, 8, 0, P, 2, 64, 0, 64, P, 512, None) == -1
+    assert b"four bits" in lib.fpn_last_error_string()
+    assert lib.fpn_flipout_stream_bits_bf16(8, 64, 64, P, P, 8, 0, P, 0, 66, 0, 64, P, 512, None) == -1
+    assert lib.fpn_flipout_stream_bits_bf16(8, 64, 64, P, P, 8, 0, None, 0, 64, 0, 64, P, 512, None) == -1
+    assert lib.fpn_flipout_stream_bits_bf16(0, 64, 64, None, None, 8, 0, None, 0, 64, 0, 64, None, 512, None) == 0
     # Flipout signs from bits: sizes, null pointers and alignment are checked before the launch
     assert lib.fpn_flipout_signs(0, None, None, None) == 0
     assert lib.fpn_flipout_signs(-1, P, P, None) == -1
