@@ -1306,10 +1306,20 @@ __global__ void flipout_signs_kernel(long n, const unsigned *__restrict__ bits, 
 // matrices through L2 for every copy.
 constexpr int kFlipCopies = 8;
 
+// BITS (chunked layouts): the signs as one bit each (set = +1) in the words of sb.bits - copy f's input sign k at
+// bit in0 + f * ldi + k (in0, ldi multiples of 4: a thread's four lie in one word), its output sign at bit
+// out0 + f * ldo + col.  As floats the signs of a pass are read from memory between the kernel's writes; as bits
+// they stay in the L2.
+struct SignBitsF32 {
+    const unsigned *bits;
+    long in0, out0;
+};
+
+template <bool BITS>
 __global__ void flipout_weights_kernel(int b, int cin, int cout, int layout, const float *__restrict__ wm,
                                        const float *__restrict__ dw, const float *__restrict__ sin, int ldi,
                                        const float *__restrict__ sout, int ldo, float *__restrict__ out,
-                                       int per_delta, long delta_stride)
+                                       int per_delta, long delta_stride, SignBitsF32 sb)
 {
     const long total = (long)cin * cout;
     const long f0 = (long)blockIdx.y * kFlipCopies;
@@ -1349,8 +1359,17 @@ __global__ void flipout_weights_kernel(int b, int cin, int cout, int layout, con
                 const float *d = dw + sample * delta_stride + src;
                 d0 = d[0]; d1 = d[cout]; d2 = d[2 * (size_t)cout]; d3 = d[3 * (size_t)cout];
             }
-            const float so = sout[f * ldo + col];
-            const float4 si = *reinterpret_cast<const float4 *>(sin + f * ldi + k);
+            float so;
+            float4 si;
+            if constexpr (BITS) {
+                const long ia = sb.in0 + f * ldi + k, io = sb.out0 + f * ldo + col;
+                const unsigned wa = sb.bits[ia >> 5] >> (ia & 31), wo = sb.bits[io >> 5] >> (io & 31);
+                si = make_float4(wa & 1u ? 1.f : -1.f, wa & 2u ? 1.f : -1.f, wa & 4u ? 1.f : -1.f, wa & 8u ? 1.f : -1.f);
+                so = wo & 1u ? 1.f : -1.f;
+            } else {
+                so = sout[f * ldo + col];
+                si = *reinterpret_cast<const float4 *>(sin + f * ldi + k);
+            }
             float4 v;
             v.x = m0 + d0 * (si.x * so);
             v.y = m1 + d1 * (si.y * so);
@@ -1575,11 +1594,38 @@ int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const
     FPN_REQUIRE(b <= 65535 * kFlipCopies, "flipout_weights: at most %d frustums per call (%d)", 65535 * kFlipCopies, b);
     FPN_REQUIRE(w_mean && w_delta && sign_in && sign_out && out, "flipout_weights: null pointer");
     const long total = (long)cin * cout;
-    hipLaunchKernelGGL(flipout_weights_kernel,
+    hipLaunchKernelGGL(flipout_weights_kernel<false>,
                        dim3((unsigned)std::min<long>((total + 255) / 256, 1024), (unsigned)((b + kFlipCopies - 1) / kFlipCopies)),
                        dim3(256), 0, as_stream(stream), b, cin, cout, layout, w_mean, w_delta, sign_in, ld_in, sign_out, ld_out,
-                       out, frustums_per_delta, delta_stride);
+                       out, frustums_per_delta, delta_stride, SignBitsF32{});
     return check_launch("fpn_flipout_weights_f32");
+}
+
+int fpn_flipout_weights_bits_f32(int b, int cin, int cout, const float *w_mean, const float *w_delta,
+                                 int frustums_per_delta, long delta_stride, const void *bits, long in_bit0, int ld_in,
+                                 long out_bit0, int ld_out, int layout, float *out, void *stream)
+{
+    FPN_REQUIRE(b >= 0 && cin >= 1 && cout >= 1, "flipout_weights_bits: bad size");
+    FPN_REQUIRE(frustums_per_delta >= 1 && delta_stride >= 0, "flipout_weights_bits: bad delta grouping %d / stride %ld",
+                frustums_per_delta, delta_stride);
+    FPN_REQUIRE(layout == 1 || layout == 2, "flipout_weights_bits: layout %d (1 chunked, 2 chunked input-tile major)", layout);
+    FPN_REQUIRE(cin % 32 == 0 && cout % 32 == 0,
+                "flipout_weights_bits: the chunked layouts need cin (%d) and cout (%d) to be multiples of 32", cin, cout);
+    FPN_REQUIRE(ld_in >= cin && ld_out >= cout && in_bit0 >= 0 && out_bit0 >= 0, "flipout_weights_bits: bad sign position or row length");
+    FPN_REQUIRE(in_bit0 % 4 == 0 && ld_in % 4 == 0,
+                "flipout_weights_bits: a copy's input signs must start at a multiple of four bits (bit %ld, %d a copy)", in_bit0, ld_in);
+    FPN_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bits) & 3) == 0,
+                "flipout_weights_bits: out must be 16-byte aligned, bits 4-byte aligned");
+    FPN_REQUIRE((long)cin * cout < (1L << 31), "flipout_weights_bits: layer too large");
+    if (b == 0) return FPN_OK;
+    FPN_REQUIRE(b <= 65535 * kFlipCopies, "flipout_weights_bits: at most %d frustums per call (%d)", 65535 * kFlipCopies, b);
+    FPN_REQUIRE(w_mean && w_delta && bits && out, "flipout_weights_bits: null pointer");
+    const long total = (long)cin * cout;
+    hipLaunchKernelGGL(flipout_weights_kernel<true>,
+                       dim3((unsigned)std::min<long>((total + 255) / 256, 1024), (unsigned)((b + kFlipCopies - 1) / kFlipCopies)),
+                       dim3(256), 0, as_stream(stream), b, cin, cout, layout, w_mean, w_delta, nullptr, ld_in, nullptr, ld_out,
+                       out, frustums_per_delta, delta_stride, SignBitsF32{static_cast<const unsigned *>(bits), in_bit0, out_bit0});
+    return check_launch("fpn_flipout_weights_bits_f32");
 }
 
 int fpn_v1_seg_tail_f32(long rows, int n, const float *point_feat, const float *group_shift,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "fpn_v1_seg_tail_f32": [_l, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "fpn_v1_obj_chain_f32": [_l, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "fpn_flipout_signs": [_l, _vp, _vp, _vp],
+    "fpn_flipout_weights_bits_f32": [_i, _i, _i, _vp, _vp, _i, _l, _vp, _l, _i, _l, _i, _i, _vp, _vp],
     "fpn_flipout_weights_f32": [_i, _i, _i, _vp, _vp, _i, _l, _vp, _i, _vp, _i, _i, _vp, _vp],
     "fpn_chain_pad_units_bf16": [],
     "fpn_chain_pack_bf16": [_i, _i, _vp, _vp, _vp, _vp],

@@ -299,7 +299,7 @@ class BayesPlan:
                               v[2][s0:s1].reshape(sp * bb, -1) if whole else v[2][s0:s1, lo:hi].reshape(sp * bb, -1))
                           for k, v in noise.items()}
                     # the same signs as bits, where the pass's copies are consecutive rows of the sign matrices
-                    if shared is not None and shared.sign_bits is not None and whole and self.precision == "bf16" \
+                    if shared is not None and shared.sign_bits is not None and whole \
                             and os.environ.get("FPN_FLIPOUT_BITS", "1") != "0":
                         nz["__bits__"] = (shared.sign_bits, s0 * b, shared.sign_pos)
                     if rep is None or rep[0] != sp:      # the repeated inputs are the same for every pass of a block
@@ -326,7 +326,12 @@ class BayesPlan:
             w, dw, si = w[:rows], dw[:, :rows], si[:, :rows]
             if si.stride(0) % 4:          # (the kernels read the signs in 16-byte groups)
                 si = si.contiguous()
-        return ops.flipout_weights(w, dw, si, so, layout)
+        bits = None
+        if "__bits__" in nz and layout != 0:
+            words, row0, pos = nz["__bits__"]
+            in0, ri, out0, ro = pos[scope]
+            bits = (words, in0 + row0 * ri, ri, out0 + row0 * ro, ro)
+        return ops.flipout_weights(w, dw, si, so, layout, bits=bits)
 
     def _chain_tensors(self, scopes, nz, layouts):
         """[w_eff, ones, bias] per layer: the `layers` table of a chain kernel."""

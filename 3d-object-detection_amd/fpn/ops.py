@@ -213,14 +213,15 @@ def flipout_signs(bits, n, out=None):
     return out
 
 
-def flipout_weights(w_mean, w_delta, sign_in, sign_out, layout, out=None):
+def flipout_weights(w_mean, w_delta, sign_in, sign_out, layout, out=None, bits=None):
     """Effective Flipout weights per frustum through fpn_flipout_weights_f32:
     W_mean + diag(sign_in[f]) . W_delta[f // per] . diag(sign_out[f]) for every row f of
     the sign matrices, in `layout` (0 row-major, 1 / 2 the chain kernels' chunk layout,
     output-tile / input-tile major).  w_delta (S, cin, cout): S Monte-Carlo samples whose
     frustum copies are stacked along the rows of the sign matrices (per = rows / S); it
     may be a row slice [:, :cin] of a taller stack and sign_in a column slice of a wider
-    matrix.  Returns (rows, cin*cout)."""
+    matrix.  bits (chunked layouts): (int32 tensor, in_bit0, ld_in, out_bit0, ld_out) - the same
+    signs as one bit each (fpn_flipout_weights_bits_f32; same matrices).  Returns (rows, cin*cout)."""
     cin, cout = w_mean.shape
     b = sign_in.shape[0]
     s = w_delta.shape[0]
@@ -228,6 +229,18 @@ def flipout_weights(w_mean, w_delta, sign_in, sign_out, layout, out=None):
         raise ValueError("w_delta must be (samples, cin, cout) with dense matrices and samples dividing %d" % b)
     if out is None:
         out = torch.empty((b, cin * cout), dtype=torch.float32, device=w_mean.device)
+    if bits is not None and layout in (1, 2):
+        words, in0, ldi, out0, ldo = bits
+        if words.dtype != torch.int32 or not words.is_contiguous():
+            raise ValueError("sign bits must be a contiguous int32 tensor")
+        if max(in0 + (b - 1) * ldi + cin, out0 + (b - 1) * ldo + cout) > 32 * words.numel():
+            raise ValueError("sign bits: the last copy's signs lie beyond the tensor")
+        with torch.cuda.device(w_mean.device):
+            _lib.check(_lib.load().fpn_flipout_weights_bits_f32(b, cin, cout, _lib.ptr(w_mean), _lib.ptr(w_delta), b // s,
+                                                                w_delta.stride(0) if s > 1 else 0, _lib.ptr(words), int(in0),
+                                                                int(ldi), int(out0), int(ldo), int(layout), _lib.ptr(out),
+                                                                _lib.stream_of(w_mean)))
+        return out
     with torch.cuda.device(w_mean.device):
         _lib.check(_lib.load().fpn_flipout_weights_f32(b, cin, cout, _lib.ptr(w_mean), _lib.ptr(w_delta), b // s,
                                                        w_delta.stride(0) if s > 1 else 0, _lib.ptr(sign_in),

@@ -338,6 +338,17 @@ int fpn_flipout_weights_f32(int b, int cin, int cout, const float *w_mean, const
                             void *stream);
 
 /*
+ * fpn_flipout_weights_f32 for the chunked layouts (1, 2) with the signs as ONE BIT each (set = +1, as
+ * fpn_flipout_signs spreads them): frustum f's input sign k is bit in_bit0 + f * ld_in + k of the 32-bit words at
+ * `bits`, its output sign c bit out_bit0 + f * ld_out + c (in_bit0 and ld_in multiples of 4).  The same matrices,
+ * bit for bit.  No counterpart in the reference (models/FPointNet_Bayes.py:54-68 keeps its signs inside
+ * tensorflow_probability's layers).
+ */
+int fpn_flipout_weights_bits_f32(int b, int cin, int cout, const float *w_mean, const float *w_delta,
+                                 int frustums_per_delta, long delta_stride, const void *bits, long in_bit0, int ld_in,
+                                 long out_bit0, int ld_out, int layout, float *out, void *stream);
+
+/*
  * Flipout's sign vectors from random bits: signs[i] = +1 where bit (i % 32) of the 32-bit word bits[i / 32] is
  * set, else -1 (i < n; bits holds (n + 31) / 32 words, 4-byte aligned; signs 16-byte aligned).  The layers of
  * models/FPointNet_Bayes.py:54-68 draw theirs inside tensorflow_probability (a Rademacher draw per input and

@@ -201,15 +201,16 @@ def test_sample_noise_layout_and_fairness(device):
     assert torch.equal(noise["dropout"], again["dropout"])
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("dropout", [False, True])
-def test_flipout_streams_from_sign_bits_are_the_same_bits(device, monkeypatch, dropout):
-    """The bf16 weight streams built from one bit per sign (fpn_flipout_stream_bits_bf16, what a plan
-    does with noise it drew itself) against the streams built from the +-1 floats spread from the same
-    bits: every end point of the whole Flipout pass the same bits.  Three samples of five frustums,
+def test_flipout_streams_from_sign_bits_are_the_same_bits(device, monkeypatch, dropout, precision):
+    """The per-copy weights built from one bit per sign (fpn_flipout_stream_bits_bf16 for the bf16
+    streams, fpn_flipout_weights_bits_f32 for the fp32 chains - what a plan does with noise it drew
+    itself) against those built from the +-1 floats spread from the same bits: every end point of the whole Flipout pass the same bits.  Three samples of five frustums,
     so the copies of a pass start at a row other than 0 in the second block."""
     from fpn import bayes, synthetic, variables
     st = variables.VariableStore(device, seed=41)
-    bp = bayes.BayesPlan(st, 4, mc_dropout=dropout, precision="bf16")
+    bp = bayes.BayesPlan(st, 4, mc_dropout=dropout, precision=precision)
     bp.CHAIN_COPIES = 10                       # two samples a pass: the second pass starts at row 10
     S, B, N = 4, 5, 128
     pc, oh = synthetic.make_frustums(B, N, 4, seed=42)

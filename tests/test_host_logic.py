@@ -99,6 +99,10 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.fpn_flipout_stream_bits_bf16(8, 64, 64, P, P, 8, 0, P, 0, 66, 0, 64, P, 512, None) == -1
     assert lib.fpn_flipout_stream_bits_bf16(8, 64, 64, P, P, 8, 0, None, 0, 64, 0, 64, P, 512, None) == -1
     assert lib.fpn_flipout_stream_bits_bf16(0, 64, 64, None, None, 8, 0, None, 0, 64, 0, 64, None, 512, None) == 0
+    assert lib.fpn_flipout_weights_bits_f32(8, 64, 64, P, P, 8, 0, P, 2, 64, 0, 64, 1, P, None) == -1
+    assert b"four bits" in lib.fpn_last_error_string()
+    assert lib.fpn_flipout_weights_bits_f32(8, 64, 64, P, P, 8, 0, P, 0, 64, 0, 64, 0, P, None) == -1     # row-major: floats only
+    assert lib.fpn_flipout_weights_bits_f32(0, 64, 64, None, None, 8, 0, None, 0, 64, 0, 64, 1, None, None) == 0
     # Flipout signs from bits: sizes, null pointers and alignment are checked before the launch
     assert lib.fpn_flipout_signs(0, None, None, None) == 0
     assert lib.fpn_flipout_signs(-1, P, P, None) == -1
