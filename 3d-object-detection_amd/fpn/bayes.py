@@ -74,8 +74,12 @@ class Noise(dict):
     all draws of a sample block by softplus(rho) in one launch instead of one per layer."""
     eps_all = None
     offsets = None
-    sign_bits = None        # the int32 words all signs were spread from, and per scope where its signs start:
-    sign_pos = None         # sign_pos[scope] = (first input bit, bits per row, first output bit, bits per row)
+    # The int32 words all signs were spread from and, per scope, where its signs start: sign_pos[scope] = (first
+    # input bit, bits per row, first output bit, bits per row).  The chain path builds its per-copy weights from
+    # these bits where it can (same values as the float views, a thirtieth of the bytes): whoever edits the float
+    # sign tensors of a drawn Noise must set sign_bits to None.
+    sign_bits = None
+    sign_pos = None
 
 
 class BayesPlan:
