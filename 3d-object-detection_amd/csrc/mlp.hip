@@ -780,7 +780,7 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         p.y += s * pin.sy;
     }
     __shared__ float part[4 * kFrRows * (kFrCols + 1)];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: the K blocks' offsets are)
     const int l31 = lane & 31, h = lane >> 5;
     const int ncb = (p.cout + kFrCols - 1) / kFrCols;
     const long row0 = (long)(blockIdx.x / ncb) * kFrRows;
@@ -800,34 +800,48 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
     const bool xvec = (p.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
     const bool svec = FLIP && (cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.sign_in) & 15) == 0);
 
+    // buffer descriptors (raw, 32-bit elements, the window as long as an offset can be) and the lane's byte
+    // offsets inside a block; the host takes this kernel for layers whose weights span less than 2 GiB only
+    const unsigned kRawFlags = 0x00020000;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, kRawFlags);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(FLIP ? p.w_delta : p.w), 0, 0x7fffffff, kRawFlags);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x + row0 * p.ldx), 0, 0x7fffffff, kRawFlags);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(FLIP ? p.sign_in : p.x), 0, 0x7fffffff, kRawFlags);
+    int va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        va[i] = ((4 * h + i) * cout + ca) * 4;
+        vb[i] = ((4 * h + i) * cout + cb) * 4;
+    }
+    const int vx = (int)((row - row0) * p.ldx + 4 * h) * 4;
+    const int vs = FLIP ? (int)((row / p.rows_per_group) * cin + 4 * h) * 4 : 0;
     struct Stage { float x[4], s[4], wa[4], wb[4], da[4], db[4]; };
     Stage ring[kFrRing];
+    // (weight indices in 32 bits - the host takes this kernel for layers below 2^31 weights only: as 64-bit products
+    // the addresses were most of the kernel's vector instructions, and beside an fp32 MFMA every one of them costs)
     auto load = [&](Stage &st, int j) {
         const int k = 8 * j + 4 * h;
-        if (k + 3 < cin) {
+        if (8 * j + 8 <= cin) {     // (wave-uniform) a whole block: no address arithmetic on the vector ALU - per-lane byte
+            // offsets made once, the block's offset a scalar; beside an fp32 MFMA every vector instruction costs
+            const int sw = 8 * j * cout * 4, sx = 8 * j * 4;
             if (xvec) {
-                const float4 v = *reinterpret_cast<const float4 *>(xrow + k);
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, vx, sx, 0));
                 st.x[0] = v.x; st.x[1] = v.y; st.x[2] = v.z; st.x[3] = v.w;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) st.x[i] = xrow[k + i];
+                for (int i = 0; i < 4; ++i) st.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vx + 4 * i, sx, 0));
             }
             if (FLIP) {
-                if (svec) {
-                    const float4 v = *reinterpret_cast<const float4 *>(srow + k);
-                    st.s[0] = v.x; st.s[1] = v.y; st.s[2] = v.z; st.s[3] = v.w;
-                } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) st.s[i] = srow[k + i];
-                }
+                for (int i = 0; i < 4; ++i) st.s[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vs + 4 * i, sx, 0));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                st.wa[i] = p.w[(long)(k + i) * cout + ca];
-                st.wb[i] = p.w[(long)(k + i) * cout + cb];       // (cb is a valid column either way; used only if two)
+                st.wa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, va[i], sw, 0));
+                st.wb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vb[i], sw, 0));
                 if (FLIP) {
-                    st.da[i] = p.w_delta[(long)(k + i) * cout + ca];
-                    st.db[i] = p.w_delta[(long)(k + i) * cout + cb];
+                    st.da[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, va[i], sw, 0));
+                    st.db[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, vb[i], sw, 0));
                 }
             }
         } else {       // the block that holds the last channel: zero activations beyond it, clamped weight rows
@@ -837,11 +851,11 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
                 const int kk = min(k + i, cin - 1);
                 st.x[i] = ok ? xrow[kk] : 0.f;
                 if (FLIP) st.s[i] = ok ? srow[kk] : 0.f;
-                st.wa[i] = p.w[(long)kk * cout + ca];
-                st.wb[i] = p.w[(long)kk * cout + cb];
+                st.wa[i] = p.w[(unsigned)(kk * cout + ca)];
+                st.wb[i] = p.w[(unsigned)(kk * cout + cb)];
                 if (FLIP) {
-                    st.da[i] = p.w_delta[(long)kk * cout + ca];
-                    st.db[i] = p.w_delta[(long)kk * cout + cb];
+                    st.da[i] = p.w_delta[(unsigned)(kk * cout + ca)];
+                    st.db[i] = p.w_delta[(unsigned)(kk * cout + cb)];
                 }
             }
         }
@@ -976,7 +990,8 @@ int launch_mlp(const MlpParams &p, hipStream_t st, unsigned samples = 1)
     const long rb = (p.rows + kBM - 1) / kBM;
     const long fr_blocks = ((p.rows + kFrRows - 1) / kFrRows) * ((p.cout + kFrCols - 1) / kFrCols);
     if constexpr (MODE != kFlipoutFold) {
-        if (p.pool_rows == 0 && fr_blocks <= 1024 && p.cin >= 32) {
+        if (p.pool_rows == 0 && fr_blocks <= 1024 && p.cin >= 32 && (long)p.cin * p.cout < (1L << 28) && p.ldx < (1 << 23) &&
+            (MODE != kFlipoutTwoPass || (p.rows / p.rows_per_group + 1) * (long)p.cin < (1L << 28))) {
             // few rows: 32 x 64 tiles, K split over the workgroup's waves
             hipLaunchKernelGGL((fewrow_mlp_kernel<MODE>), dim3((unsigned)fr_blocks, samples), dim3(kMlpThreads), 0, st, p);
             return check_launch("fpn_shared_mlp(few rows)");
