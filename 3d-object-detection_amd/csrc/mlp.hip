@@ -779,6 +779,13 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         if (p.group_bias) p.group_bias += s * pin.sgb;
         p.y += s * pin.sy;
     }
+#ifdef FPN_FEWROW_STAMPS     // timing-only build: cycle stamps of one wave into the output (wrong results)
+    long long stamp[6];
+    stamp[0] = clock64();
+#define FPN_FRSTAMP(i) stamp[i] = clock64()
+#else
+#define FPN_FRSTAMP(i)
+#endif
     __shared__ float part[4 * kFrRows * (kFrCols + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: the K blocks' offsets are)
     const int l31 = lane & 31, h = lane >> 5;
@@ -815,6 +822,10 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
     }
     const int vx = (int)((row - row0) * p.ldx + 4 * h) * 4;
     const int vs = FLIP ? (int)((row / p.rows_per_group) * cin + 4 * h) * 4 : 0;
+    // the epilogue's per-column constants, requested now (unconditional loads - a weight stands in where a layer has
+    // no scale or shift): read where they are used, they were a trip to memory at the kernel's end
+    const int col_early = min(col0 + (tid & 63), cout - 1);
+    const float sc_early = (p.scale ? p.scale : p.w)[col_early], sh_early = (p.shift ? p.shift : p.w)[col_early];
     struct Stage { float x[4], s[4], wa[4], wb[4], da[4], db[4]; };
     Stage ring[kFrRing];
     // (weight indices in 32 bits - the host takes this kernel for layers below 2^31 weights only: as 64-bit products
@@ -885,6 +896,7 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
     if (npipe > 0) {
 #pragma unroll
         for (int s = 0; s < kFrRing; ++s) load(ring[s], b0 + s);
+        FPN_FRSTAMP(1);
         __builtin_amdgcn_sched_barrier(0);
         for (int j0 = 0; j0 < npipe; j0 += kFrRing) {
 #pragma unroll
@@ -901,6 +913,7 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         step(ring[0]);
     }
 
+    FPN_FRSTAMP(2);
     // partial tiles -> LDS: register r of tile u holds row (r&3) + 8(r>>2) + 4h, column 32u + l31.
     // The Flipout form's second product goes through the SAME buffer after the first has been
     // summed (two more barriers, half the LDS: 33 KB, under the 64 KiB a kernel gets by default).
@@ -927,8 +940,10 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
     };
     float v[8], d[8];
     put(acc);
+    FPN_FRSTAMP(3);
     __syncthreads();
     sum(v);
+    FPN_FRSTAMP(4);
     if (FLIP) {
         __syncthreads();
         put(accd);
@@ -936,8 +951,8 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         sum(d);
     }
     if (col >= cout) return;
-    const float sc = p.scale ? p.scale[col] : 1.f;
-    const float sh = p.shift ? p.shift[col] : 0.f;
+    const float sc = p.scale ? sc_early : 1.f;
+    const float sh = p.shift ? sh_early : 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int rr = (tid >> 6) + 4 * i;
@@ -950,6 +965,12 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
         if (p.relu) y = fmaxf(y, 0.f);
         p.y[rw * p.ldy + col] = y;
     }
+#ifdef FPN_FEWROW_STAMPS
+    stamp[5] = clock64();
+    __syncthreads();        // (the workgroup's own results are out: the stamps go over the first of them)
+    if (blockIdx.x == 0 && tid == 64)
+        for (int i = 0; i < 6; ++i) reinterpret_cast<long long *>(p.y)[i] = stamp[i];
+#endif
 }
 
 // y[g,c] = max over the blocks_per_group partial rows of group g
