@@ -11,7 +11,8 @@ from fpn import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 rows, cin, cout = 1024, int(os.environ.get("CIN", 1027)), int(os.environ.get("COUT", 512))
-x = torch.randn((rows, cin + (-cin) % 4), device=dev)[:, :cin]
+ldx = int(os.environ.get("LDX", cin + (-cin) % 4))       # row stride of x in floats
+x = torch.randn((rows, ldx), device=dev)[:, :cin]
 w = torch.randn((cin, cout), device=dev)
 names = ["ring start", "K loop", "partials to LDS", "barrier + sum", "epilogue"]
 for _ in range(4):
