@@ -830,44 +830,47 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
     Stage ring[kFrRing];
     // (weight indices in 32 bits - the host takes this kernel for layers below 2^31 weights only: as 64-bit products
     // the addresses were most of the kernel's vector instructions, and beside an fp32 MFMA every one of them costs)
-    auto load = [&](Stage &st, int j) {
-        const int k = 8 * j + 4 * h;
-        if (8 * j + 8 <= cin) {     // (wave-uniform) a whole block: no address arithmetic on the vector ALU - per-lane byte
-            // offsets made once, the block's offset a scalar; beside an fp32 MFMA every vector instruction costs
-            const int sw = 8 * j * cout * 4, sx = 8 * j * 4;
-            if (xvec) {
-                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, vx, sx, 0));
-                st.x[0] = v.x; st.x[1] = v.y; st.x[2] = v.z; st.x[3] = v.w;
-            } else {
+    // a whole block (8 j + 8 <= cin, wave-uniform): no address arithmetic on the vector ALU - per-lane byte offsets
+    // made once, the block's offset a scalar; beside an fp32 MFMA every vector instruction costs.  Kept apart from
+    // the ragged block's loads: with both behind one branch inside the ring, the compiler put the ragged path's
+    // wait for its loads where the paths join, and every stage waited for the loads it had just requested
+    auto load_full = [&](Stage &st, int j) {
+        const int sw = 8 * j * cout * 4, sx = 8 * j * 4;
+        if (xvec) {
+            const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, vx, sx, 0));
+            st.x[0] = v.x; st.x[1] = v.y; st.x[2] = v.z; st.x[3] = v.w;
+        } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) st.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vx + 4 * i, sx, 0));
-            }
+            for (int i = 0; i < 4; ++i) st.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vx + 4 * i, sx, 0));
+        }
+        if (FLIP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st.s[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vs + 4 * i, sx, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            st.wa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, va[i], sw, 0));
+            st.wb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vb[i], sw, 0));
             if (FLIP) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st.s[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vs + 4 * i, sx, 0));
+                st.da[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, va[i], sw, 0));
+                st.db[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, vb[i], sw, 0));
             }
+        }
+    };
+    // the block that holds the last channel: zero activations beyond it, clamped weight rows
+    auto load_ragged = [&](Stage &st, int j) {
+        const int k = 8 * j + 4 * h;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                st.wa[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, va[i], sw, 0));
-                st.wb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, vb[i], sw, 0));
-                if (FLIP) {
-                    st.da[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, va[i], sw, 0));
-                    st.db[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, vb[i], sw, 0));
-                }
-            }
-        } else {       // the block that holds the last channel: zero activations beyond it, clamped weight rows
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = k + i < cin;
-                const int kk = min(k + i, cin - 1);
-                st.x[i] = ok ? xrow[kk] : 0.f;
-                if (FLIP) st.s[i] = ok ? srow[kk] : 0.f;
-                st.wa[i] = p.w[(unsigned)(kk * cout + ca)];
-                st.wb[i] = p.w[(unsigned)(kk * cout + cb)];
-                if (FLIP) {
-                    st.da[i] = p.w_delta[(unsigned)(kk * cout + ca)];
-                    st.db[i] = p.w_delta[(unsigned)(kk * cout + cb)];
-                }
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = k + i < cin;
+            const int kk = min(k + i, cin - 1);
+            st.x[i] = ok ? xrow[kk] : 0.f;
+            if (FLIP) st.s[i] = ok ? srow[kk] : 0.f;
+            st.wa[i] = p.w[(unsigned)(kk * cout + ca)];
+            st.wb[i] = p.w[(unsigned)(kk * cout + cb)];
+            if (FLIP) {
+                st.da[i] = p.w_delta[(unsigned)(kk * cout + ca)];
+                st.db[i] = p.w_delta[(unsigned)(kk * cout + cb)];
             }
         }
     };
@@ -892,10 +895,11 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
     // ring of kFrRing K blocks; the stages are fenced so that the scheduler keeps a refill
     // behind the use of the stage it overwrites and ahead of the next stage's use
     const int n = b1 - b0;
-    const int npipe = n > 0 ? (n / kFrRing) * kFrRing : 0;
+    const int nfull = max(0, min(b1, cin >> 3) - b0);        // the wave's whole blocks (the ring takes only these)
+    const int npipe = (nfull / kFrRing) * kFrRing;
     if (npipe > 0) {
 #pragma unroll
-        for (int s = 0; s < kFrRing; ++s) load(ring[s], b0 + s);
+        for (int s = 0; s < kFrRing; ++s) load_full(ring[s], b0 + s);
         FPN_FRSTAMP(1);
         __builtin_amdgcn_sched_barrier(0);
         for (int j0 = 0; j0 < npipe; j0 += kFrRing) {
@@ -903,13 +907,17 @@ __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams
             for (int s = 0; s < kFrRing; ++s) {
                 step(ring[s]);
                 __builtin_amdgcn_sched_barrier(0);
-                load(ring[s], b0 + min(j0 + s + kFrRing, npipe - 1));
+                load_full(ring[s], b0 + min(j0 + s + kFrRing, npipe - 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    for (int j = npipe; j < n; ++j) {
-        load(ring[0], b0 + j);
+    for (int j = npipe; j < nfull; ++j) {
+        load_full(ring[0], b0 + j);
+        step(ring[0]);
+    }
+    for (int j = nfull; j < n; ++j) {
+        load_ragged(ring[0], b0 + j);
         step(ring[0]);
     }
 
