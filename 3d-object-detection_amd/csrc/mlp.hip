@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_stream_kernel(con
 // output tile and its four waves SPLIT K: wave w multiplies the w-th quarter of the
 // input channels, with both MFMA operands loaded straight from memory into registers
 // (activations: 16 bytes per lane, 4 consecutive channels of its row; weights: one dword
-// per lane and MFMA, a row of 32 consecutive columns) through a register ring three
+// per lane and MFMA, a row of 32 consecutive columns) through a register ring three or four
 // K blocks deep - no LDS, no barrier inside the K loop.  The four partial tiles are then
 // summed through LDS in a fixed order (deterministic) and the usual epilogue runs on the
 // sum.  32 x 64 tiles give 256 workgroups for a 1024 x 512 layer.
@@ -762,13 +762,17 @@ __global__ __launch_bounds__(kMlpThreads) void shared_mlp_bf16_stream_kernel(con
 // MODE kFlipoutTwoPass: a second accumulator takes (x * s_in) . dW; the epilogue adds it
 // times s_out.
 // ---------------------------------------------------------------------------
-constexpr int kFrRows = 32, kFrCols = 64, kFrRing = 3;
+constexpr int kFrRows = 32, kFrCols = 64;
 
 template <int MODE>
 __global__ __launch_bounds__(kMlpThreads) void fewrow_mlp_kernel(const MlpParams pin)
 {
     static_assert(MODE == kPlain || MODE == kFlipoutTwoPass, "plain or two-product Flipout");
     constexpr bool FLIP = MODE == kFlipoutTwoPass;
+    // K blocks in flight per wave: four (of 12 registers) for the plain product - whole blocks per wave come in
+    // multiples of four for the layer widths met here, what is left over runs one by one - three (of 24) with
+    // Flipout's second product (measured: 62 / 67 / 72 us for v1's layers with 4 / 3 / 5, 298 / 290 / 310 with Flipout)
+    constexpr int kFrRing = FLIP ? 3 : 4;
     MlpParams p = pin;
     if (FLIP) {
         const long s = blockIdx.y;
